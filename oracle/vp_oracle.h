@@ -1,0 +1,107 @@
+/*
+ * vp_oracle.h -- CPU restatement ("oracle") of the DamRsn/VocoderProject DSP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under vocoderproject_amd/ (the product) may include,
+ * link, import or call anything in oracle/.  Allowed users: tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.
+ *
+ * PARITY STATUS
+ *   The reference (Source/ *.cpp) includes "../JuceLibraryCode/JuceHeader.h" (JUCE 5.4.7,
+ *   Vocoder.jucer:3; un-vendored, .gitignore:1-2) and foleys_gui_magic.  Neither is in this
+ *   image, and building it against hand-written stand-in headers is not allowed, so the
+ *   reference is UNBUILDABLE here.  The reference has no tests, fixtures or golden vectors.
+ *     - pinned (tests/golden/methods_vectors.npz, generated from the reference's own
+ *       Notebook/methods.py in the build container): biased autocorrelation, Levinson-Durbin,
+ *       YIN difference function + threshold walk, first-frame analysis pitch marks,
+ *       sine window, chromatic note table.
+ *     - pinned (SURVEY.md Appendix A / section 3.1 known answers recorded from a survey-session run of the
+ *       compiled reference): Notes::getClosestFreq KATs, prepareToPlay geometry (latency,
+ *       inSize, outSize, tauMax at 44.1 kHz and 48 kHz), "ch2 returns 0".
+ *     - PARITY UNPINNED: end-to-end processBlock() output, the pitch-mark state machine beyond
+ *       the first voiced frame, PSOLA, and the JUCE arithmetic surface (getRMSLevel, Decibels,
+ *       WindowingFunction hann), which is restated from JUCE 5.4.x documented semantics.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/Source/).
+ */
+#ifndef VP_ORACLE_H
+#define VP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPO_MARK_CAP 64     /* fixed capacity of the pitch-mark arrays (reference: reserve(20), PitchProcess.cpp:104-109) */
+#define VPO_ORDER_MAX 100   /* lpcVoice / lpcPitch range end, PluginProcessor.cpp:53-57 */
+#define VPO_ORDER_MAX_SYNTH 30 /* lpcSynth range end, PluginProcessor.cpp:59 */
+#define VPO_NOTES_CAP 88    /* Notes.cpp:27 freq.reserve(88) */
+
+typedef struct vpo vpo;
+
+/* Per-pitch-frame trace record (what SURVEY.md 8c(3) calls "pitch traces"). */
+typedef struct {
+    int gated;              /* 1: silence gate closed at this frame start (PitchProcess.cpp:208-214) */
+    int period, prevPeriod, prevVoicedPeriod, periodNew;
+    double pitch, prevPitch, beta, closestFreq;
+    int nAn, nSt;
+    int anMarks[VPO_MARK_CAP];
+    int stMarks[VPO_MARK_CAP];
+    double a[VPO_ORDER_MAX + 1];
+} vpo_pitch_frame;
+
+/* ---- plugin-shaped surface (PluginProcessor.cpp) ---- */
+vpo *vpo_create(void);                                        /* ctor + createParameterLayout :14-73 */
+void vpo_destroy(vpo *o);
+/* ids: gainPitch gainVoice gainSynth gainVoc lpcVoice lpcPitch lpcSynth keyPitch pitchBool vocBool.
+ * Returns 0, or -1 for an unknown id / out-of-range value. */
+int vpo_set_param(vpo *o, const char *id, float value);
+float vpo_get_param(const vpo *o, const char *id);
+int vpo_prepare_to_play(vpo *o, double sampleRate, int samplesPerBlock);   /* :144-184 */
+/* Explicit geometry (restates :172-183 with explicit sizes).  Returns 0 or a negative
+ * code when the reference would assert (overlap not 0.5/0.75, F % (F-H) != 0, ...). */
+int vpo_prepare_explicit(vpo *o, double sampleRate, int samplesPerBlock,
+                         int frameLenPitch, int hopPitch, int wlenVoc, int hopVoc);
+/* In-place 3 x N float buffer: ch0 voice -> out L, ch1 synth L -> out R, ch2 synth R -> 0.
+ * ch1/ch2 may be NULL (sidechain absent, MyBuffer.cpp:93-102); then out R is not written. :203-234 */
+int vpo_process_block(vpo *o, float *ch0, float *ch1, float *ch2);
+int vpo_get_latency(const vpo *o);
+int vpo_get_geometry(const vpo *o, int out[12]); /* N,F,H,C,W,h,toKeep,latency,inSize,outSize,tauMax,chunksPerFrame */
+/* Frames started during the most recent process_block call. */
+int vpo_trace_count(const vpo *o);
+int vpo_trace_get(const vpo *o, int i, vpo_pitch_frame *out);
+/* Number of times a reference undefined-behaviour site (SURVEY Q2/Q3/empty back()/yinTemp[tauMax]) was
+ * reached since prepare; [0]=Q2 anMarks[size], [1]=Q3 negative clIdx, [2]=back() of empty vector,
+ * [3]=yinTemp[tauMax] read, [4]=mark capacity > reserve(20) */
+void vpo_ub_counters(const vpo *o, long out[5]);
+void vpo_set_ftz(vpo *o, int on);   /* ScopedNoDenormals (:205); default on */
+
+/* ---- primitives exposed for known-answer tests ---- */
+/* LPC.cpp:44-97 */
+void vpo_biased_autocorr(const double *ring, int inSize, int currCounter, int startSample,
+                         int order, int wlen, const double *anWindow, double *r);
+/* LPC.cpp:107-148; a, aPrev have aLen entries (only [0..order] are written unless |r0|<1e-9) */
+void vpo_levinson_durbin(const double *r, double *a, double *aPrev, int order, int aLen);
+/* Notes.cpp:43-70; returns table size; freq[size] holds the popped element (Notes.cpp:69) */
+int vpo_notes_build(int key, double fMin, double fMax, double *freq);
+/* Notes.cpp:79-110 (lookup only, table given) */
+double vpo_notes_closest(const double *freq, int size, double pitch);
+/* JUCE dsp::WindowingFunction<double>::fillWindowingTables(..., hann, false) */
+void vpo_hann(double *w, int n);
+/* VocoderProcess.cpp:95-135, "sine"; returns 0 or -1 (invalid overlap) */
+int vpo_vocoder_windows(int wlen, int hop, double *anWindow, double *stWindow);
+/* PitchProcess.cpp:889-905 */
+int vpo_pitch_st_window(int frameLen, int hop, double *stWindow);
+/* PitchProcess.cpp:350-403 on a linear signal: x has frameLen + tauMax samples, x[tauMax] is frame pos 0 */
+void vpo_yin_temp_linear(const double *x, int frameLen, int tauMax, double *yinTemp);
+/* PitchProcess.cpp:411-448 threshold walk on a given yinTemp (tauMax+1 entries readable); returns period (0 = unvoiced) */
+int vpo_yin_pick(const double *yinTemp, int tauMax, double fS, double fMax, double yinTol);
+/* KAT hook: PitchProcess.cpp:455-567 for a frame following an unvoiced one; returns the mark count */
+int vpo_kat_pitch_marks(const double *x, int F, int H, double fs, int period, int *marksOut);
+/* JUCE Decibels */
+double vpo_gain_to_db(double gain);              /* gainToDecibels(double, -100) */
+float vpo_db_to_gain_f(float dB);                /* decibelsToGain(float, -59.0f) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
