@@ -1,0 +1,142 @@
+/*
+ * vp_amd.h -- C ABI of libvp_amd.so: the MI355X (gfx950) batch implementation of the
+ * DamRsn/VocoderProject DSP hot path (PitchProcess pitch corrector + LPC/VocoderProcess
+ * cross-synthesis behind VocoderAudioProcessor::processBlock()).
+ *
+ * One handle = a BATCH of S independent plugin instances (one per audio stream) living on one
+ * GPU.  Every entry point is what the reference's host code would bind through FFI for this
+ * path; the reference interface each one replaces is cited as file:line relative to
+ * /root/reference/Source/.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Threading: one caller thread per handle (the reference runs processBlock() on one audio
+ * thread per instance, PluginProcessor.cpp:203).  Parameters are snapshotted at call entry
+ * (the reference reads std::atomic<float> values with load(), :214-230).
+ * No allocation happens in vp_process_block*() (reference: all vectors are sized in
+ * prepareToPlay, PitchProcess.cpp:95-121).
+ */
+#ifndef VP_AMD_H
+#define VP_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP_ABI_VERSION 1
+
+/* status codes (the reference has none: it prints to std::cerr and assert(false)s) */
+enum {
+    VP_OK = 0,
+    VP_ERR_INVALID_ARG = -1,     /* null pointer, non-positive size, parameter out of its range (PluginProcessor.cpp:41-69) */
+    VP_ERR_NOT_PREPARED = -2,    /* processBlock before prepareToPlay */
+    VP_ERR_INVALID_OVERLAP = -3, /* VocoderProcess.cpp:110-114 "Invalid overlap": (wlen-hop)/wlen must be 0.5 or 0.75 */
+    VP_ERR_GEOMETRY = -4,        /* frameLen % (frameLen-hop) != 0 (PitchProcess.cpp:91-92), tauMax > samplesToKeep (:364), ... */
+    VP_ERR_ORDER = -5,           /* LPC order above its parameter maximum (VocoderProcess.cpp:145-148,161-164) */
+    VP_ERR_NO_DEVICE = -6,       /* no usable HIP device: this library has NO CPU fallback */
+    VP_ERR_HIP = -7,             /* a HIP runtime call failed; see vp_last_error() */
+    VP_ERR_OOM = -8
+};
+
+/* The ten plugin parameters, same ids, ranges and defaults as
+ * VocoderAudioProcessor::createParameterLayout() (PluginProcessor.cpp:37-73).
+ * They apply to every stream of the handle. */
+typedef struct vp_params {
+    float gainPitch;   /* dB  [-60, 6]   default   0 */
+    float gainVoice;   /* dB  [-60, 6]   default -60 (dry voice off) */
+    float gainSynth;   /* dB  [-60, 6]   default -60 (dry carrier off) */
+    float gainVoc;     /* dB  [-60, 6]   default   0 */
+    int lpcVoice;      /* [2, 100] default 40; re-read every vocoder window (VocoderProcess.cpp:193-194) */
+    int lpcPitch;      /* [2, 100] default 15; read ONLY at prepare (PitchProcess.cpp:70) */
+    int lpcSynth;      /* [2, 30]  default  5 */
+    int keyPitch;      /* 0..11 = major key on A, A#, ... G#; 12 = chromatic (default) (Notes.h:18) */
+    int pitchBool;     /* 1: pitch corrector on (default) */
+    int vocBool;       /* 1: vocoder on (default) */
+} vp_params;
+
+/* Per-stream pitch-tracker state, for tracing/parity tests (the reference keeps these as private
+ * members, PitchProcess.h:108-131). */
+#define VP_MARK_CAP 64
+typedef struct vp_pitch_state {
+    int period, prevPeriod, prevVoicedPeriod, periodNew;
+    int nAn, nSt, stMarkIdx, gateOpen;
+    double pitch, prevPitch, beta, closestFreq;
+    int anMarks[VP_MARK_CAP];
+    int stMarks[VP_MARK_CAP];
+    double a[101];
+} vp_pitch_state;
+
+typedef struct vp_handle vp_handle;
+
+/* createPluginFilter() (PluginProcessor.cpp:272-275): a batch of plugin instances on HIP device
+ * `device`.  Fails with VP_ERR_NO_DEVICE when no GPU is present. */
+int vp_create(int device, vp_handle **out);
+int vp_destroy(vp_handle *h);
+
+/* treeState.getRawParameterValue(id)->store(v) for all ten ids at once (PluginProcessor.cpp:37-73).
+ * May be called between blocks at any time; lpcPitch only takes effect at the next prepare. */
+int vp_set_params(vp_handle *h, const vp_params *p);
+int vp_get_params(const vp_handle *h, vp_params *p);
+void vp_default_params(vp_params *p);
+
+/* VocoderAudioProcessor::prepareToPlay(sampleRate, samplesPerBlock) (PluginProcessor.cpp:144-184)
+ * for n_streams instances: derives the vocoder/pitch geometry from the sample rate (:159-170),
+ * allocates and zeroes all per-stream state in HBM. */
+int vp_prepare_to_play(vp_handle *h, double sample_rate, int samples_per_block, int n_streams);
+
+/* Same with explicit geometry: pitchProcess.prepare(fs,100,800,F,H,N,-60),
+ * vocoderProcess.prepare(W,h,"sine",-60), myBuffer.prepare(N,F,max(F,W),fs,1,2,2)
+ * (PluginProcessor.cpp:172-181; both prepare()s are public: PitchProcess.h:40, VocoderProcess.h:29). */
+int vp_prepare_explicit(vp_handle *h, double sample_rate, int samples_per_block, int n_streams,
+                        int frame_len_pitch, int hop_pitch, int wlen_voc, int hop_voc);
+
+/* processBlock(AudioBuffer<float>&, MidiBuffer&) (PluginProcessor.cpp:203-234) for every stream.
+ * Host buffers, planar float32:  in  [n_streams][3][N]  (ch0 voice, ch1/ch2 side-chain L/R),
+ *                                out [n_streams][2][N]  (L, R).
+ * Synchronous: returns when `out` is filled. */
+int vp_process_block(vp_handle *h, const float *in, float *out);
+
+/* The reference's exact in-place form: io [n_streams][3][N]; on return ch0/ch1 hold out L/R and
+ * ch2 is zero (MyBuffer.cpp:115 buffer.clear()). Host buffer, synchronous. */
+int vp_process_block_inplace(vp_handle *h, float *io);
+
+/* Device-resident form (the multi-GPU / throughput path): d_in, d_out are device pointers with
+ * the layouts above; kernels are enqueued on `hip_stream` (a hipStream_t, may be NULL = default
+ * stream) and the call returns without synchronising. */
+int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void *hip_stream);
+
+/* AudioProcessor::getLatencySamples() after setLatencySamples(max(F, W)) (PluginProcessor.cpp:175,183). */
+int vp_get_latency(const vp_handle *h);
+/* N, F, H, C, W, h, samplesToKeep, latency, inSize, outSize, tauMax, chunksPerFrame
+ * (MyBuffer.h:37-43 getters + PitchProcess/VocoderProcess geometry). */
+int vp_get_geometry(const vp_handle *h, int out[12]);
+int vp_get_num_streams(const vp_handle *h);
+
+/* Copies one stream's pitch-tracker state to the host (synchronises). */
+int vp_read_pitch_state(vp_handle *h, int stream, vp_pitch_state *out);
+
+/* hipDeviceSynchronize on the handle's device. */
+int vp_synchronize(vp_handle *h);
+
+/* Kernel timing with HIP events on the launch stream (bench.py's roofline figures).
+ * vp_profile_enable(h, 1) brackets every kernel launch with events; vp_profile_read returns, per
+ * kernel slot, the accumulated milliseconds and launch count since the last reset.
+ * Slots: 0 ingest+gate, 1 vocoder, 2 pitch, 3 emit. */
+#define VP_NUM_KERNEL_SLOTS 4
+int vp_profile_enable(vp_handle *h, int on);
+int vp_profile_read(vp_handle *h, double ms[VP_NUM_KERNEL_SLOTS], long launches[VP_NUM_KERNEL_SLOTS], int reset);
+const char *vp_kernel_slot_name(int slot);
+
+/* Counts, over all streams since prepare, how often a kernel reached one of the reference's
+ * undefined-behaviour sites (back() of an empty vector, yinTemp[tauMax]):
+ * same meaning as the oracle's counters. Synchronises. */
+int vp_read_ub_counters(vp_handle *h, long out[5]);
+
+const char *vp_error_string(int code);
+const char *vp_last_error(const vp_handle *h);
+int vp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_AMD_H */

@@ -1,0 +1,7 @@
+"""vocoderproject_amd -- MI355X-native batch implementation of the DamRsn/VocoderProject DSP hot path.
+
+Product code: csrc/ (HIP kernels + C ABI, built into libvp_amd.so), processor.py (host mirror of the
+reference's plugin surface), synth.py (synthetic streams), dist.py (stream sharding across ranks).
+Nothing here imports oracle/.
+"""
+from .processor import BatchVocoderProcessor, VpError, load_library, PARAM_IDS, KEYS  # noqa: F401

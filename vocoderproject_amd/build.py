@@ -1,0 +1,49 @@
+"""Builds libvp_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m vocoderproject_amd.build [--force]
+
+-ffp-contract=off is part of the numerics contract: the kernels reproduce the reference's IEEE
+double arithmetic operation by operation (no FMA contraction), see csrc/vp_kernels.hip.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libvp_amd.so")
+SOURCES = ["vp_kernels.hip", "vp_capi.hip"]
+DEPS = SOURCES + ["vp_common.h", "vp_kernels.h"]
+ARCH = "gfx950"
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in DEPS] + [os.path.join(ROOT, "include", "vp_amd.h")]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+           f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd += [os.path.join(CSRC, f) for f in SOURCES]
+    cmd += ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,567 @@
+// vp_capi.hip -- host side of libvp_amd.so: the C ABI declared in include/vp_amd.h.
+//
+// Mirrors VocoderAudioProcessor (PluginProcessor.cpp) for a batch of streams: parameter storage
+// (:37-73), prepareToPlay geometry + allocation (:144-184) and the processBlock orchestration
+// (:203-234: fill -> vocoder -> pitch (or silence) -> dry voice -> dry synth -> out), with the
+// per-block counters of MyBuffer / VocoderProcess / PitchProcess kept on the host because they
+// advance identically for every stream.  There is no CPU fallback: without a HIP device every
+// entry point that needs one fails with VP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vp_amd.h"
+#include "vp_kernels.h"
+
+struct vp_handle {
+    int device = 0;
+    bool prepared = false;
+    vp_params params;
+    VpGeom g;
+    VpDev d;
+    // MyBuffer counters (MyBuffer.h:72-79), VocoderProcess::startSample, PitchProcess::startSample/nChunk
+    int inCounter = 0, outCounter = 0, currCounter = 0, vStart = 0, pStart = 0, nChunk = 0;
+    std::vector<void *> allocs;
+    float *stageIn = nullptr, *stageOut = nullptr;
+    hipStream_t ownStream = nullptr;
+    int vocWaves = 8;
+    size_t vocLds = 0, pitchLds = 0;
+    bool prof = false;
+    struct EvPair { hipEvent_t a, b; int slot; };
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> evPool;
+    double profMs[VP_NUM_KERNEL_SLOTS] = {0, 0, 0, 0};
+    long profN[VP_NUM_KERNEL_SLOTS] = {0, 0, 0, 0};
+    std::string lastError;
+};
+
+static int fail_hip(vp_handle *h, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (h) h->lastError = buf;
+    return VP_ERR_HIP;
+}
+#define HIPCHK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail_hip((h), _e, #call); } while (0)
+
+extern "C" int vp_abi_version(void) { return VP_ABI_VERSION; }
+
+extern "C" const char *vp_error_string(int code)
+{
+    switch (code) {
+    case VP_OK: return "ok";
+    case VP_ERR_INVALID_ARG: return "invalid argument or parameter out of range";
+    case VP_ERR_NOT_PREPARED: return "process called before prepare";
+    case VP_ERR_INVALID_OVERLAP: return "Invalid overlap";                    // VocoderProcess.cpp:112
+    case VP_ERR_GEOMETRY: return "invalid frame geometry";
+    case VP_ERR_ORDER: return "LPC order is larger than OrderMax";            // VocoderProcess.cpp:146,162
+    case VP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case VP_ERR_HIP: return "HIP runtime error";
+    case VP_ERR_OOM: return "out of device memory";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *vp_last_error(const vp_handle *h) { return h ? h->lastError.c_str() : ""; }
+
+extern "C" const char *vp_kernel_slot_name(int slot)
+{
+    static const char *n[VP_NUM_KERNEL_SLOTS] = {"vp_k_ingest_gate", "vp_k_vocoder", "vp_k_pitch", "vp_k_emit"};
+    return (slot >= 0 && slot < VP_NUM_KERNEL_SLOTS) ? n[slot] : "";
+}
+
+extern "C" void vp_default_params(vp_params *p)
+{
+    // createParameterLayout defaults, PluginProcessor.cpp:41-69
+    p->gainPitch = 0.0f; p->gainVoice = -60.0f; p->gainSynth = -60.0f; p->gainVoc = 0.0f;
+    p->lpcVoice = 40; p->lpcPitch = 15; p->lpcSynth = 5; p->keyPitch = 12;
+    p->pitchBool = 1; p->vocBool = 1;
+}
+
+static bool params_valid(const vp_params *p)
+{
+    auto gain_ok = [](float v) { return v >= -60.0f && v <= 6.0f; };
+    return gain_ok(p->gainPitch) && gain_ok(p->gainVoice) && gain_ok(p->gainSynth) && gain_ok(p->gainVoc) &&
+           p->lpcVoice >= 2 && p->lpcVoice <= VP_ORDER_MAX && p->lpcPitch >= 2 && p->lpcPitch <= VP_ORDER_MAX &&
+           p->lpcSynth >= 2 && p->lpcSynth <= VP_ORDER_MAX_SYNTH && p->keyPitch >= 0 && p->keyPitch <= 12 &&
+           (p->pitchBool == 0 || p->pitchBool == 1) && (p->vocBool == 0 || p->vocBool == 1);
+}
+
+extern "C" int vp_create(int device, vp_handle **out)
+{
+    if (!out) return VP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return VP_ERR_INVALID_ARG;
+    vp_handle *h = new vp_handle();
+    h->device = device;
+    vp_default_params(&h->params);
+    memset(&h->g, 0, sizeof h->g);
+    memset(&h->d, 0, sizeof h->d);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return VP_ERR_NO_DEVICE;
+    }
+    *out = h;
+    return VP_OK;
+}
+
+static void free_all(vp_handle *h)
+{
+    for (void *p : h->allocs) (void)hipFree(p);
+    h->allocs.clear();
+    h->stageIn = h->stageOut = nullptr;
+    h->prepared = false;
+}
+
+extern "C" int vp_destroy(vp_handle *h)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    free_all(h);
+    for (auto &p : h->pending) { h->evPool.push_back(p.a); h->evPool.push_back(p.b); }
+    for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
+    if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+    delete h;
+    return VP_OK;
+}
+
+extern "C" int vp_set_params(vp_handle *h, const vp_params *p)
+{
+    if (!h || !p || !params_valid(p)) return VP_ERR_INVALID_ARG;
+    h->params = *p;
+    return VP_OK;
+}
+
+extern "C" int vp_get_params(const vp_handle *h, vp_params *p)
+{
+    if (!h || !p) return VP_ERR_INVALID_ARG;
+    *p = h->params;
+    return VP_OK;
+}
+
+// ---- prepare-time tables (host libm, the same calls the reference makes) -------------------------
+
+// JUCE dsp::WindowingFunction<double>::fillWindowingTables(w, n, hann, false): symmetric Hann
+static void fill_hann(double *w, int n)
+{
+    for (int i = 0; i < n; i++)
+        w[i] = 0.5 - 0.5 * std::cos((double)(2 * (long)i) * 3.141592653589793238 / (double)(n - 1));
+}
+
+// VocoderProcess::setWindows("sine") (VocoderProcess.cpp:95-135); PI is the truncated literal (:13)
+static int fill_voc_window(std::vector<double> &w, int wlen, int hop)
+{
+    const double PI_REF = 3.14159265;
+    double overlap = double(wlen - hop) / double(wlen);
+    double overlapFactor = 1.0;
+    if (std::fabs(overlap - 0.75) < std::pow(10, -10)) overlapFactor = 1.0 / std::sqrt(2);
+    if (std::fabs(overlap - 0.75) > std::pow(10, -10) && std::fabs(overlap - 0.5) > std::pow(10, -10))
+        return VP_ERR_INVALID_OVERLAP;
+    w.resize(wlen);
+    for (int i = 0; i < wlen; i++) w[i] = overlapFactor * std::sin((i + 0.5) * PI_REF / double(wlen));
+    return VP_OK;
+}
+
+// PitchProcess::buildWindows (PitchProcess.cpp:889-905): half-Hann | ones | half-Hann
+static int fill_pitch_st_window(std::vector<double> &w, int frameLen, int hop)
+{
+    double overlap = ((double)(frameLen - hop)) / ((double)(frameLen));
+    int ov = (int)std::round(overlap * frameLen);
+    int nh = 2 * ov;
+    if (nh > frameLen || nh < 2) return VP_ERR_GEOMETRY;
+    std::vector<double> hw(nh);
+    fill_hann(hw.data(), nh);
+    w.assign(frameLen, 1.0);
+    for (int i = 0; i < ov; i++) w[i] = hw[i];
+    for (int i = 0; i < ov; i++) w[frameLen - ov + i] = hw[ov + i];
+    return VP_OK;
+}
+
+// Notes::buildFreqVect (Notes.cpp:43-70); tab[size] keeps the popped element (:69, read at :99)
+static int build_notes(int key, double fMin, double fMax, double *tab)
+{
+    static const int intervals[7] = {2, 2, 1, 2, 2, 2, 1};
+    int n = 0, i = 0;
+    double f = 27.5;
+    f = f * std::pow(2, double(key) / 12.0);
+    double factorSemiTone = std::pow(2, 1.0 / 12);
+    while (n == 0 || tab[n - 1] < fMax) {
+        if (key != 12) f = f * std::pow(factorSemiTone, intervals[i % 7]);
+        else f = f * factorSemiTone;
+        if (f > fMin) { if (n < VP_NOTES_STRIDE) tab[n] = f; n++; }
+        i += 1;
+    }
+    return n - 1;
+}
+
+// Decibels::gainToDecibels(getRMSLevel(...)) < silenceThresholdDb as a function of sum(x^2)
+static bool gate_closed(double sum, int n, double silenceDb)
+{
+    double rms = std::sqrt(sum / n);
+    double db = rms > 0.0 ? std::max(-100.0, std::log10(rms) * 20.0) : -100.0;
+    return db < silenceDb;
+}
+static double gate_threshold_sum(int n, double silenceDb)
+{
+    // the verdict is monotone in sum: bisect over the bit patterns of the positive doubles
+    uint64_t lo = 0, hi;
+    double big = 1e300;
+    memcpy(&hi, &big, 8);
+    while (lo + 1 < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        double v;
+        memcpy(&v, &mid, 8);
+        if (gate_closed(v, n, silenceDb)) lo = mid; else hi = mid;
+    }
+    double v;
+    memcpy(&v, &hi, 8);
+    return v;      // smallest sum for which the gate is open
+}
+
+// Decibels::decibelsToGain<float>(dB, -59.0f)
+static float db_to_gain_f(float dB) { return dB > -59.0f ? std::pow(10.0f, dB * 0.05f) : 0.0f; }
+
+template <typename T>
+static int dev_alloc(vp_handle *h, T **p, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) { h->lastError = "hipMalloc failed"; return VP_ERR_OOM; }
+    h->allocs.push_back(q);
+    if (zero) HIPCHK(h, hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    *p = (T *)q;
+    return VP_OK;
+}
+template <typename T>
+static int dev_upload(vp_handle *h, const T **p, const std::vector<T> &v)
+{
+    T *q = nullptr;
+    int rc = dev_alloc(h, &q, v.size(), false);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *p = q;
+    return VP_OK;
+}
+#define RC(x) do { int _rc = (x); if (_rc) { free_all(h); return _rc; } } while (0)
+
+extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F, int H, int W, int hop)
+{
+    if (!h || N <= 0 || S <= 0 || F <= 0 || H <= 0 || W <= 0 || hop <= 0 || !(fs > 0)) return VP_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    (void)hipDeviceSynchronize();
+    free_all(h);
+
+    const double fMin = 100, fMax = 800, silenceDb = -60.0;                  // PluginProcessor.cpp:148,172
+    VpGeom g;
+    memset(&g, 0, sizeof g);
+    g.S = S; g.N = N; g.F = F; g.H = H; g.W = W; g.h = hop; g.fs = fs;
+    g.C = F - H;                                                             // PitchProcess.cpp:91-92
+    if (g.C <= 0 || F % g.C != 0) return VP_ERR_GEOMETRY;
+    g.cpf = F / g.C;
+    if (g.cpf < 2) return VP_ERR_GEOMETRY;
+    g.toKeep = F;                                                            // PluginProcessor.cpp:176
+    g.latency = std::max(F, W);                                              // :175
+    g.inSize = g.toKeep + N + g.latency;                                     // MyBuffer.cpp:46-48
+    g.outSize = N + g.latency;
+    g.tauMax = (int)std::ceil(fs / fMin);                                    // PitchProcess.cpp:100
+    if (g.tauMax > g.toKeep) return VP_ERR_GEOMETRY;                         // YIN reads back to startSample - tauMax (:364)
+    g.tau0 = (int)std::floor(fs / fMax);
+    if (g.tau0 < 1) return VP_ERR_GEOMETRY;
+    g.eLen = g.toKeep + F + (g.cpf - 1) * g.C;
+    g.orderPitch = h->params.lpcPitch;                                       // read once (PitchProcess.cpp:70)
+    g.bufferIdxMax = g.latency + N;                                          // PitchProcess.cpp:138
+    g.delta = 0.94; g.yinTol = 0.25;                                         // :76,84
+    g.gateThrSum = gate_threshold_sum(g.inSize, silenceDb);
+    g.levEps = std::pow(10, -9);
+    g.eeFloor = std::pow(10, -4);
+
+    std::vector<double> vocWin, pitchSt;
+    int rc = fill_voc_window(vocWin, W, hop);
+    if (rc) return rc;
+    rc = fill_pitch_st_window(pitchSt, F, H);
+    if (rc) return rc;
+
+    // Hann(2T+1) for every possible PSOLA period (PitchProcess.cpp:878-882), T = 1..tauMax
+    std::vector<int> hannOff(g.tauMax + 1, 0);
+    size_t tot = 0;
+    for (int T = 1; T <= g.tauMax; T++) { hannOff[T] = (int)tot; tot += 2 * (size_t)T + 1; }
+    std::vector<double> hannTab(tot);
+    for (int T = 1; T <= g.tauMax; T++) fill_hann(hannTab.data() + hannOff[T], 2 * T + 1);
+
+    std::vector<double> notes(13 * VP_NOTES_STRIDE, 0.0);
+    std::vector<int> notesN(13);
+    for (int k = 0; k < 13; k++) notesN[k] = build_notes(k, fMin, fMax, notes.data() + (size_t)k * VP_NOTES_STRIDE);
+
+    // LDS budgets
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    const size_t ldsMax = std::min<size_t>((size_t)prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536, 160 * 1024);
+    h->pitchLds = vp_pitch_lds_bytes(g);
+    if (h->pitchLds > ldsMax) { h->lastError = "pitch frame does not fit LDS"; return VP_ERR_GEOMETRY; }
+    int nw = 8;
+    while (nw > 1 && vp_voc_lds_bytes(W, nw) > ldsMax) nw--;
+    if (vp_voc_lds_bytes(W, nw) > ldsMax) { h->lastError = "vocoder window does not fit LDS"; return VP_ERR_GEOMETRY; }
+    h->vocWaves = nw;
+    h->vocLds = vp_voc_lds_bytes(W, nw);
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_vocoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vocLds));
+
+    VpDev d;
+    memset(&d, 0, sizeof d);
+    RC(dev_alloc(h, &d.voiceRing, (size_t)S * g.inSize));
+    RC(dev_alloc(h, &d.synthRing, (size_t)S * 2 * g.inSize));
+    RC(dev_alloc(h, &d.outAcc, (size_t)S * g.outSize));
+    RC(dev_alloc(h, &d.gate, (size_t)S * 2));
+    RC(dev_alloc(h, &d.pitch, (size_t)S));
+    RC(dev_alloc(h, &d.eFrame, (size_t)S * g.eLen));
+    RC(dev_alloc(h, &d.outEFrame, (size_t)S * F));
+    RC(dev_alloc(h, &d.yFrame, (size_t)S * F));
+    RC(dev_alloc(h, &d.EeArr, (size_t)S * 20));
+    RC(dev_alloc(h, &d.ub, (size_t)5));
+    RC(dev_upload(h, &d.vocWin, vocWin));
+    RC(dev_upload(h, &d.pitchStWin, pitchSt));
+    RC(dev_upload(h, &d.hannTab, hannTab));
+    RC(dev_upload(h, &d.hannOff, hannOff));
+    RC(dev_upload(h, &d.notes, notes));
+    RC(dev_upload(h, &d.notesN, notesN));
+    RC(dev_alloc(h, &h->stageIn, (size_t)S * 3 * N, false));
+    RC(dev_alloc(h, &h->stageOut, (size_t)S * 3 * N, false));
+    {   // PitchProcess::prepare initial members (:76-85): everything 0 except beta = 1
+        std::vector<VpPitchState> init(S);
+        memset(init.data(), 0, init.size() * sizeof(VpPitchState));
+        for (auto &p : init) p.beta = 1;
+        if (hipMemcpy(d.pitch, init.data(), init.size() * sizeof(VpPitchState), hipMemcpyHostToDevice) != hipSuccess) {
+            free_all(h);
+            return VP_ERR_HIP;
+        }
+    }
+    h->g = g;
+    h->d = d;
+    h->inCounter = g.toKeep + g.latency;                                     // MyBuffer.cpp:60-62
+    h->outCounter = 0;
+    h->currCounter = g.toKeep;
+    h->vStart = 0; h->pStart = 0; h->nChunk = 0;                             // VocoderProcess.cpp:39, PitchProcess.cpp:85,90
+    h->prepared = true;
+    (void)hipDeviceSynchronize();
+    return VP_OK;
+}
+
+extern "C" int vp_prepare_to_play(vp_handle *h, double sampleRate, int samplesPerBlock, int nStreams)
+{
+    if (!h || !(sampleRate > 0)) return VP_ERR_INVALID_ARG;
+    // PluginProcessor.cpp:159-170
+    double ratioSR = sampleRate / 44100.0;
+    int hopVoc = (int)std::floor(128.0 * ratioSR);
+    int wlenVoc = 4 * hopVoc;
+    int corres_256 = (int)std::floor(256.0 * ratioSR);
+    int hopPitch = 3 * corres_256;
+    int frameLenPitch = 4 * corres_256;
+    return vp_prepare_explicit(h, sampleRate, samplesPerBlock, nStreams, frameLenPitch, hopPitch, wlenVoc, hopVoc);
+}
+
+static hipEvent_t get_event(vp_handle *h)
+{
+    if (!h->evPool.empty()) { hipEvent_t e = h->evPool.back(); h->evPool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    vp_handle *h; hipStream_t st; int slot; hipEvent_t a, b;
+    ProfScope(vp_handle *h_, hipStream_t st_, int slot_) : h(h_), st(st_), slot(slot_)
+    {
+        if (h->prof) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope()
+    {
+        if (h->prof) { (void)hipEventRecord(b, st); h->pending.push_back({a, b, slot}); }
+    }
+};
+
+static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace)
+{
+    const VpGeom &g = h->g;
+    const vp_params P = h->params;                                           // snapshot at call entry
+    if (P.lpcVoice > VP_ORDER_MAX || P.lpcSynth > VP_ORDER_MAX_SYNTH) return VP_ERR_ORDER;
+    VpCall c;
+    memset(&c, 0, sizeof c);
+    c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
+    c.orderVoice = P.lpcVoice; c.orderSynth = P.lpcSynth; c.key = P.keyPitch;
+    c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
+    c.dryOn = ((double)P.gainVoice > -59.0);                                 // PluginProcessor.cpp:226
+    c.synthOn = ((double)P.gainSynth > -59.0);                               // :229
+    c.gainPitch = (double)db_to_gain_f(P.gainPitch);
+    c.gainVoc = (double)db_to_gain_f(P.gainVoc);
+    c.gainVoice = (double)db_to_gain_f(P.gainVoice);
+    c.gainSynth = (double)db_to_gain_f(P.gainSynth);
+    // VocoderProcess::process (VocoderProcess.cpp:173-183): windows while startSample < N
+    c.vStart = h->vStart;
+    c.nWin = 0;
+    if (c.vocOn && h->vStart < g.N) c.nWin = (g.N - h->vStart + g.h - 1) / g.h;
+    // PitchProcess::process (PitchProcess.cpp:166-196): chunk steps while startSample < N
+    c.pStart = h->pStart; c.nChunk0 = h->nChunk;
+    c.nSteps = 0;
+    if (c.pitchOn && h->pStart < g.N) c.nSteps = (g.N - h->pStart + g.C - 1) / g.C;
+
+    {
+        ProfScope ps(h, st, 0);
+        hipLaunchKernelGGL(vp_k_ingest_gate, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_in);
+    }
+    if (c.nWin > 0) {
+        ProfScope ps(h, st, 1);
+        int nw = std::min(h->vocWaves, c.nWin);
+        hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(64 * nw), vp_voc_lds_bytes(g.W, nw), st, g, c, h->d);
+    }
+    if (c.nSteps > 0) {
+        ProfScope ps(h, st, 2);
+        hipLaunchKernelGGL(vp_k_pitch, dim3(g.S), dim3(512), h->pitchLds, st, g, c, h->d);
+    }
+    {
+        ProfScope ps(h, st, 3);
+        hipLaunchKernelGGL(vp_k_emit, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_out);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
+
+    // counters: VocoderProcess.cpp:176-182, PitchProcess.cpp:169-195, MyBuffer.cpp:129-132
+    if (c.vocOn) h->vStart = h->vStart + c.nWin * g.h - g.N;
+    if (c.pitchOn) {
+        int nChunk = h->nChunk;
+        for (int i = 0; i < c.nSteps; i++) {
+            if (nChunk % g.cpf == g.cpf - 1) nChunk = 1 % g.cpf;
+            else nChunk += 1;
+        }
+        h->nChunk = nChunk;
+        h->pStart = h->pStart + c.nSteps * g.C - g.N;
+    }
+    h->outCounter = (h->outCounter + g.N) % g.outSize;
+    h->inCounter = (h->inCounter + g.N) % g.inSize;
+    h->currCounter = (h->currCounter + g.N) % g.inSize;
+    return VP_OK;
+}
+
+extern "C" int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void *hip_stream)
+{
+    if (!h || !d_in || !d_out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0);
+}
+
+extern "C" int vp_process_block(vp_handle *h, const float *in, float *out)
+{
+    if (!h || !in || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
+    HIPCHK(h, hipMemcpyAsync(h->stageIn, in, nIn * sizeof(float), hipMemcpyHostToDevice, h->ownStream));
+    int rc = process_device(h, h->stageIn, h->stageOut, h->ownStream, 0);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->stageOut, nOut * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
+    HIPCHK(h, hipStreamSynchronize(h->ownStream));
+    return VP_OK;
+}
+
+extern "C" int vp_process_block_inplace(vp_handle *h, float *io)
+{
+    if (!h || !io) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    const size_t n = (size_t)h->g.S * 3 * h->g.N;
+    HIPCHK(h, hipMemcpyAsync(h->stageIn, io, n * sizeof(float), hipMemcpyHostToDevice, h->ownStream));
+    int rc = process_device(h, h->stageIn, h->stageOut, h->ownStream, 1);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(io, h->stageOut, n * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
+    HIPCHK(h, hipStreamSynchronize(h->ownStream));
+    return VP_OK;
+}
+
+extern "C" int vp_get_latency(const vp_handle *h) { return (h && h->prepared) ? h->g.latency : VP_ERR_NOT_PREPARED; }
+
+extern "C" int vp_get_geometry(const vp_handle *h, int out[12])
+{
+    if (!h || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    const VpGeom &g = h->g;
+    int v[12] = {g.N, g.F, g.H, g.C, g.W, g.h, g.toKeep, g.latency, g.inSize, g.outSize, g.tauMax, g.cpf};
+    memcpy(out, v, sizeof v);
+    return VP_OK;
+}
+
+extern "C" int vp_get_num_streams(const vp_handle *h) { return (h && h->prepared) ? h->g.S : VP_ERR_NOT_PREPARED; }
+
+extern "C" int vp_synchronize(vp_handle *h)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());
+    return VP_OK;
+}
+
+extern "C" int vp_read_pitch_state(vp_handle *h, int stream, vp_pitch_state *out)
+{
+    if (!h || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (stream < 0 || stream >= h->g.S) return VP_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());
+    VpPitchState ps;
+    int gate[2];
+    HIPCHK(h, hipMemcpy(&ps, h->d.pitch + stream, sizeof ps, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(gate, h->d.gate + 2 * stream, sizeof gate, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->period = ps.period; out->prevPeriod = ps.prevPeriod; out->prevVoicedPeriod = ps.prevVoicedPeriod;
+    out->periodNew = ps.periodNew; out->nAn = ps.nAn; out->nSt = ps.nSt; out->stMarkIdx = ps.stMarkIdx;
+    out->gateOpen = gate[0];
+    out->pitch = ps.pitch; out->prevPitch = ps.prevPitch; out->beta = ps.beta; out->closestFreq = ps.closestFreq;
+    memcpy(out->anMarks, ps.anMarks, sizeof out->anMarks);
+    memcpy(out->stMarks, ps.stMarks, sizeof out->stMarks);
+    memcpy(out->a, ps.a, sizeof out->a);
+    return VP_OK;
+}
+
+extern "C" int vp_read_ub_counters(vp_handle *h, long out[5])
+{
+    if (!h || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());
+    unsigned long long v[5];
+    HIPCHK(h, hipMemcpy(v, h->d.ub, sizeof v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; i++) out[i] = (long)v[i];
+    return VP_OK;
+}
+
+extern "C" int vp_profile_enable(vp_handle *h, int on)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    h->prof = on != 0;
+    return VP_OK;
+}
+
+extern "C" int vp_profile_read(vp_handle *h, double ms[VP_NUM_KERNEL_SLOTS], long launches[VP_NUM_KERNEL_SLOTS], int reset)
+{
+    if (!h || !ms || !launches) return VP_ERR_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());
+    for (auto &p : h->pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { h->profMs[p.slot] += t; h->profN[p.slot] += 1; }
+        h->evPool.push_back(p.a);
+        h->evPool.push_back(p.b);
+    }
+    h->pending.clear();
+    for (int i = 0; i < VP_NUM_KERNEL_SLOTS; i++) { ms[i] = h->profMs[i]; launches[i] = h->profN[i]; }
+    if (reset) for (int i = 0; i < VP_NUM_KERNEL_SLOTS; i++) { h->profMs[i] = 0; h->profN[i] = 0; }
+    return VP_OK;
+}

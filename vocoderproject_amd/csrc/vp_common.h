@@ -1,0 +1,81 @@
+// vp_common.h -- host/device shared layout of the batch plugin state.
+//
+// Data layout in HBM (S = streams of the handle):
+//   voiceRing  f32 [S][inSize]      MyBuffer::mInputVoice, same PHYSICAL ring positions as the
+//                                   reference (MyBuffer.cpp:34-65); float storage is exact because
+//                                   the ring only ever holds float inputs widened to double (:74-105)
+//   synthRing  f32 [S][2][inSize]   MyBuffer::mInputSynth
+//   outAcc     f64 [S][outSize]     MyBuffer::mOutput; ONE accumulator for both channels: the
+//                                   vocoder and the pitch corrector add the same value to every
+//                                   channel (VocoderProcess.cpp:291-295, PitchProcess.cpp:332);
+//                                   the channels only diverge in addSynth, applied at emit time
+//   pitch      VpPitchState [S]     PitchProcess private members (PitchProcess.h:108-138)
+//   eFrame/outEFrame/yFrame f64     per-stream frame buffers that live across blocks
+//   EeArr      f64 [S][2][10]       VocoderProcess::EeVoiceArr / EeSynthArr
+// Counters (inCounter/outCounter/currCounter, startSample, nChunk) advance identically for all
+// streams, so they live on the host and travel as kernel arguments (VpCall).
+#pragma once
+#include <stddef.h>
+
+#define VP_MARKS 64
+#define VP_ORDER_MAX 100
+#define VP_ORDER_MAX_SYNTH 30
+#define VP_NOTES_STRIDE 89     // Notes.cpp:27 reserve(88) + the popped element
+
+struct VpGeom {
+    int S, N, F, H, C, cpf, W, h, toKeep, latency, inSize, outSize, tauMax;
+    int eLen;            // toKeep + F + (cpf-1)*C : the part of eFrame the reference ever writes
+    int orderPitch;      // lpcPitch as read at prepare (PitchProcess.cpp:70)
+    int tau0;            // floor(fS/fMax) (PitchProcess.cpp:429)
+    int bufferIdxMax;    // latency + N (PitchProcess.cpp:138)
+    int pad0;
+    double fs, delta, yinTol;
+    double gateThrSum;   // smallest sum(x^2) over the ring for which 20log10(rms) >= -60 dB
+    double levEps;       // pow(10,-9)  LPC.cpp:110
+    double eeFloor;      // pow(10,-4)  VocoderProcess.cpp:270
+};
+
+struct VpCall {
+    int inCounter, outCounter, currCounter;
+    int vStart, nWin;            // vocoder windows start at vStart + j*h, j < nWin
+    int pStart, nChunk0, nSteps; // pitch chunk steps start at pStart + j*C
+    int orderVoice, orderSynth, key;
+    int pitchOn, vocOn, dryOn, synthOn, inplace;
+    double gainPitch, gainVoc, gainVoice, gainSynth;   // (double) of the float gains
+};
+
+struct VpPitchState {
+    int period, prevPeriod, prevVoicedPeriod, periodNew;
+    int stMarkIdx, nAnMarksOv, nStMarksOv, gateOpen;
+    double pitch, prevPitch, prevVoicedPitch, closestFreq, prevClosestFreq, beta;
+    int nAn, nSt, nPrevAn, nPrevSt;
+    int anMarks[VP_MARKS], stMarks[VP_MARKS], prevAnMarks[VP_MARKS], prevStMarks[VP_MARKS];
+    double a[VP_ORDER_MAX + 1];
+};
+
+struct VpDev {
+    float *voiceRing;
+    float *synthRing;
+    double *outAcc;
+    int *gate;               // [S][2] voice open, synth(ch0) open
+    VpPitchState *pitch;
+    double *eFrame, *outEFrame, *yFrame;
+    double *EeArr;
+    const double *vocWin;    // [W]  anWindow == stWindow ("sine", VocoderProcess.cpp:125-129)
+    const double *pitchStWin;// [F]
+    const double *hannTab;   // hann(2T+1) for T = 1..tauMax, concatenated
+    const int *hannOff;      // [tauMax+1]
+    const double *notes;     // [13][VP_NOTES_STRIDE]
+    const int *notesN;       // [13]
+    unsigned long long *ub;  // [5]
+};
+
+// doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+static inline size_t voc_wave_doubles(int W)
+{
+    return (size_t)4 * W + 3 * (VP_ORDER_MAX + 1) + 3 * (VP_ORDER_MAX_SYNTH + 1) + 4;
+}
+#define VP_VOC_SHARED_DOUBLES(W) ((size_t)(W) + 20 + 16 + 8)

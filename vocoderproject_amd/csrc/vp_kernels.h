@@ -1,0 +1,21 @@
+// vp_kernels.h -- kernel prototypes shared by vp_kernels.hip and vp_capi.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vp_common.h"
+
+__global__ void vp_k_ingest_gate(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in);
+__global__ void vp_k_vocoder(VpGeom g, VpCall c, VpDev d);
+__global__ void vp_k_pitch(VpGeom g, VpCall c, VpDev d);
+__global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
+
+// bytes of dynamic LDS vp_k_pitch needs for a geometry
+static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
+{
+    size_t dbl = (size_t)(g.toKeep + g.F) + g.eLen + 2 * (size_t)g.F + 2 * (size_t)(g.tauMax + 1) + 2 * (VP_ORDER_MAX + 1);
+    return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64;
+}
+static inline size_t vp_voc_lds_bytes(int W, int nWaves)
+{
+    return (VP_VOC_SHARED_DOUBLES(W) + (size_t)nWaves * voc_wave_doubles(W)) * sizeof(double);
+}

@@ -1,0 +1,836 @@
+// vp_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the batch pitch-corrector / vocoder.
+//
+// Numerics contract: every value that feeds a discrete decision or reaches the output is
+// computed in IEEE double in the reference's own operation order (no FMA contraction: this file
+// is compiled with -ffp-contract=off), so results are bit-identical to the CPU restatement of
+// the reference and decisions (YIN threshold walk, pitch marks, nearest note, gate) cannot flip.
+// Parallelism is taken only where the reference's order leaves it free:
+//   * across streams (one workgroup per stream),
+//   * across YIN lags / autocorrelation lags (each lag is its own left-to-right sum),
+//   * across output samples of FIR / PSOLA / overlap-add,
+//   * across vocoder windows of a block (one wavefront per window).
+// Citations are file:line relative to /root/reference/Source/.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "vp_common.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+
+__device__ __forceinline__ int ring_pos(int curr, int idx, int inSize)
+{
+    // MyBuffer::getVoiceSample index math (MyBuffer.cpp:152): (currCounter + idx + inSize) % inSize
+    int p = curr + idx + inSize;
+    p %= inSize;
+    return p;
+}
+
+struct MinIdx { double v; int i; };
+
+__device__ __forceinline__ MinIdx min_first(MinIdx a, MinIdx b)
+{
+    // argExt semantics (PitchProcess.cpp:752-776): strict '<' while scanning upwards keeps the
+    // FIRST minimum, i.e. the lexicographic minimum of (value, index).
+    if (b.v < a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+__device__ __forceinline__ MinIdx wave_min_first(MinIdx m)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        MinIdx o;
+        o.v = __shfl_down(m.v, off, WAVE);
+        o.i = __shfl_down(m.i, off, WAVE);
+        m = min_first(m, o);
+    }
+    return m;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: ingest + silence gate.  MyBuffer::fillInputBuffers (MyBuffer.cpp:74-105) and the whole-ring
+// RMS gate used by both processes (MyBuffer.cpp:258-261,299-302; VocoderProcess.cpp:199-204;
+// PitchProcess.cpp:208).  One workgroup per stream.
+//
+// The reference sums x^2 left to right over the PHYSICAL ring; its verdict is
+// "sum_seq < gateThrSum" (gateThrSum is found on the host by bisection through the same libm
+// calls).  A tree sum T differs from the sequential one by at most ~2 n eps T, so T decides unless
+// it is within that band of the threshold, in which case one lane redoes the exact sequential sum.
+__global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in)
+{
+    const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    float *vr = d.voiceRing + (size_t)s * g.inSize;
+    float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
+    float *sr1 = sr0 + g.inSize;
+    const float *xin = in + (size_t)s * 3 * g.N;
+    for (int i = tid; i < g.N; i += nt) {
+        int p = (c.inCounter + i) % g.inSize;
+        vr[p] = xin[i];
+        sr0[p] = xin[g.N + i];
+        sr1[p] = xin[2 * g.N + i];
+    }
+    __syncthreads();   // own-workgroup global writes are visible to the workgroup after the barrier
+
+    double sv = 0.0, ss = 0.0;
+    for (int i = tid; i < g.inSize; i += nt) {
+        double a = (double)vr[i], b = (double)sr0[i];
+        sv += a * a;
+        ss += b * b;
+    }
+    sv = wave_sum(sv);
+    ss = wave_sum(ss);
+    __shared__ double red[2][8];
+    if ((tid & 63) == 0) { red[0][tid >> 6] = sv; red[1][tid >> 6] = ss; }
+    __syncthreads();
+    if (tid < 2) {
+        const float *ring = tid == 0 ? vr : sr0;
+        double T = 0.0;
+        for (int w = 0; w < nt / WAVE; w++) T += red[tid][w];
+        const double band = T * (double)(2 * g.inSize + 64) * 1.1102230246251565e-16 * 1.5;
+        int open;
+        if (T - g.gateThrSum > band) open = 1;
+        else if (g.gateThrSum - T > band) open = 0;
+        else {
+            double seq = 0.0;                       // AudioBuffer::getRMSLevel order
+            for (int i = 0; i < g.inSize; i++) { double a = (double)ring[i]; seq += a * a; }
+            open = !(seq < g.gateThrSum);
+        }
+        d.gate[s * 2 + tid] = open;
+    }
+    if (!c.pitchOn && tid == 0) {
+        // PitchProcess::silence() (PitchProcess.cpp:146-158), called when pitchBool is off
+        VpPitchState *ps = d.pitch + s;
+        ps->nAn = 0; ps->nSt = 0;
+        ps->prevPitch = 0; ps->prevPeriod = 0; ps->pitch = 0; ps->period = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Levinson-Durbin, LPC.cpp:107-148, executed by ONE lane on LDS arrays (a, aPrev sized aLen).
+__device__ void levinson_durbin(const double *r, double *a, double *aPrev, int order, int aLen, double eps)
+{
+    if (fabs(r[0]) < eps) {                        // :110-114 (floating abs intended)
+        for (int i = 0; i < aLen; i++) a[i] = 0.0;
+        a[0] = 1.0;
+        return;
+    }
+    a[0] = 1.0;
+    a[1] = r[1] / r[0];
+    for (int p = 2; p < order + 1; p++) {
+        for (int j = 1; j < p; j++) aPrev[j] = a[j];
+        double rho_a = 0.0, r_a = 0.0;
+        for (int i = 1; i < p; i++) {
+            rho_a += r[p - i] * a[i];
+            r_a += r[i] * a[i];
+        }
+        double k = (r[p] - rho_a) / (r[0] - r_a);
+        for (int i = 1; i < p; i++) a[i] = aPrev[i] - k * aPrev[p - i];
+        a[p] = k;
+    }
+    for (int i = 1; i < order + 1; i++) a[i] *= -1.;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: vocoder.  VocoderProcess::process/processWindow (VocoderProcess.cpp:173-223), one workgroup
+// per stream, one wavefront per window, windows of a block taken in rounds of (waves per group).
+//
+// Per-wave LDS (W = window length):
+//   A  [W] f64   first: voice f32[W] | synth f32[W] (raw samples for the autocorrelation);
+//                later: eSynth (residual of the carrier)
+//   B  [W] f64   first: xwV = voice*anWindow; later: out (IIR output, then scaled for the OLA)
+//   Cc [W] f64   xwS = synth*anWindow
+//   D  [W] f64   eVoice (only its energy is used)
+//   r/a/aPrev for voice (101 each) and synth (31 each), energies
+
+__global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
+{
+    extern __shared__ double smem[];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, nWaves = blockDim.x >> 6;
+    if (!(d.gate[s * 2 + 0] && d.gate[s * 2 + 1])) return;     // :199-204, whole workgroup
+
+    const int W = g.W, oV = c.orderVoice, oS = c.orderSynth;
+    double *win = smem;                       // [W] shared by all waves
+    double *hist = win + W;                   // [2][10] EeVoiceArr, EeSynthArr
+    double *roundE = hist + 20;               // [2][8]
+    double *gArr = roundE + 16;               // [8]
+    double *wbase = gArr + 8 + (size_t)wave * voc_wave_doubles(W);
+    double *A = wbase, *B = A + W, *Cc = B + W, *D = Cc + W;
+    float *xv = (float *)A, *xsy = xv + W;
+    double *rV = D + W, *aV = rV + (VP_ORDER_MAX + 1), *aPV = aV + (VP_ORDER_MAX + 1);
+    double *rS = aPV + (VP_ORDER_MAX + 1), *aS = rS + (VP_ORDER_MAX_SYNTH + 1), *aPS = aS + (VP_ORDER_MAX_SYNTH + 1);
+
+    for (int i = tid; i < W; i += blockDim.x) win[i] = d.vocWin[i];
+    if (tid < 20) hist[tid] = d.EeArr[(size_t)s * 20 + tid];
+    const float *vr = d.voiceRing + (size_t)s * g.inSize;
+    const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
+    double *acc = d.outAcc + (size_t)s * g.outSize;
+    __syncthreads();
+
+    for (int w0 = 0; w0 < c.nWin; w0 += nWaves) {
+        const int w = w0 + wave;
+        const bool active = w < c.nWin;
+        const int nAct = min(nWaves, c.nWin - w0);
+        const int start = c.vStart + w * g.h;
+
+        if (active) {
+            for (int i = lane; i < W; i += WAVE) {
+                int p = ring_pos(c.currCounter, start + i, g.inSize);
+                float v = vr[p], y = sr0[p];
+                xv[i] = v; xsy[i] = y;
+                B[i] = (double)v * win[i];               // x*anWindow, LPC.cpp:61 tmp / filterFIR product
+                Cc[i] = (double)y * win[i];
+            }
+        }
+        __syncthreads();
+
+        // biaisedAutoCorr (LPC.cpp:44-97) for voice lags 0..oV and synth lags 0..oS: one lane per
+        // lag, each lag its own left-to-right sum over n.
+        if (active) {
+            const int nLags = oV + 1 + oS + 1;
+            for (int q = lane; q < nLags; q += WAVE) {
+                const bool isV = q <= oV;
+                const int m = isV ? q : q - (oV + 1);
+                const double *xw = isV ? B : Cc;
+                const float *x = isV ? xv : xsy;
+                double sum = 0.0;
+                for (int n = 0; n < W - m; n++) sum += xw[n] * (double)x[n + m] * win[n + m];
+                sum /= (double)W;
+                if (isV) rV[m] = sum; else rS[m] = sum;
+            }
+        }
+        __syncthreads();
+        if (active && lane < 2)                          // voice on lane 0, carrier on lane 1, in lockstep
+            levinson_durbin(lane == 0 ? rV : rS, lane == 0 ? aV : aS, lane == 0 ? aPV : aPS, lane == 0 ? oV : oS,
+                            lane == 0 ? VP_ORDER_MAX + 1 : VP_ORDER_MAX_SYNTH + 1, g.levEps);
+        __syncthreads();
+
+        // filterFIR (VocoderProcess.cpp:235-251): zero history left of the window.
+        if (active) {
+            for (int i = lane; i < W; i += WAVE) {
+                double e = aV[0] * B[i];                 // a[0]*x*w with a[0] == 1
+                int kmax = min(oV, i);
+                for (int k = 1; k <= kmax; k++) e += B[i - k] * aV[k];
+                D[i] = e;
+            }
+        }
+        __syncthreads();     // A (raw samples) is dead from here: it becomes eSynth
+        if (active) {
+            for (int i = lane; i < W; i += WAVE) {
+                double e = aS[0] * Cc[i];
+                int kmax = min(oS, i);
+                for (int k = 1; k <= kmax; k++) e += Cc[i - k] * aS[k];
+                A[i] = e;
+            }
+        }
+        __syncthreads();
+        if (active && lane < 2) {                        // E += e[i]*e[i], left to right (:250)
+            const double *e = lane == 0 ? D : A;
+            double E = 0.0;
+            for (int i = 0; i < W; i++) E += e[i] * e[i];
+            roundE[lane * 8 + wave] = E;
+        }
+        __syncthreads();
+
+        // filterIIR part 1 (VocoderProcess.cpp:264-275): 10-deep energy histories, window by window.
+        if (tid == 0) {
+            for (int j = 0; j < nAct; j++) {
+                for (int i = 9; i > 0; i--) { hist[i] = hist[i - 1]; hist[10 + i] = hist[10 + i - 1]; }
+                hist[0] = roundE[j];
+                hist[10] = roundE[8 + j];
+                double gg = 0.0;
+                if (roundE[8 + j] > g.eeFloor) {
+                    double sv = 0, ss = 0;
+                    for (int i = 0; i < 10; i++) sv += hist[i];
+                    for (int i = 0; i < 10; i++) ss += hist[10 + i];
+                    gg = sqrt(sv / ss);
+                }
+                gArr[j] = gg;
+            }
+        }
+        __syncthreads();
+
+        // filterIIR part 2 (:277-286): all-pole recursion, serial in i; one lane per window.
+        if (active && lane == 0) {
+            const double gg = gArr[wave];
+            for (int i = 0; i < W; i++) {
+                double o = gg * A[i];
+                int kmax = min(oV, i);
+                for (int k = 1; k <= kmax; k++) o -= B[i - k] * aV[k];
+                B[i] = o;
+            }
+        }
+        __syncthreads();
+        if (active)                                      // gainVoc * out[i] * stWindow[i] (:291-295)
+            for (int i = lane; i < W; i += WAVE) B[i] = c.gainVoc * B[i] * win[i];
+        __syncthreads();
+
+        // overlap-add in gather form: every output sample adds its covering windows in window order,
+        // which is the order of the reference's addOutSample calls (MyBuffer.cpp:181-191).
+        {
+            const int start0 = c.vStart + w0 * g.h;
+            const int span = (nAct - 1) * g.h + W;
+            for (int t = tid; t < span; t += blockDim.x) {
+                int pos = (c.outCounter + start0 + t) % g.outSize;
+                double v = acc[pos];
+                int jlo = max(0, (t - W + g.h) / g.h), jhi = min(nAct - 1, t / g.h);
+                for (int j = jlo; j <= jhi; j++) {
+                    int i = t - j * g.h;
+                    if (i >= 0 && i < W) {
+                        const double *Bj = gArr + 8 + (size_t)j * voc_wave_doubles(W) + W;
+                        v += Bj[i];
+                    }
+                }
+                acc[pos] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 20) d.EeArr[(size_t)s * 20 + tid] = hist[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: pitch corrector.  PitchProcess::process (PitchProcess.cpp:166-196) for one block: one
+// workgroup per stream walks the block's chunk steps in order.
+//
+// LDS: xs   [toKeep+F]  voice samples idx in [startSample-toKeep, startSample+F) of the step
+//      eF   [eLen]      eFrame      (frame position p <-> eF[toKeep+p], PitchProcess.cpp:698)
+//      oE   [F]         outEFrame
+//      yF   [F]         yFrame
+//      dY   [tauMax+1]  yinTemp (+ guard slot), cum [tauMax]
+//      r, aPrev [101]
+struct PitchLds {
+    double *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev;
+    VpPitchState *st;
+    MinIdx *part;      // [8]
+    int *ishare;       // [4]
+};
+
+// argExt over frame positions [lo, hi) (PitchProcess.cpp:752-776), whole workgroup cooperates.
+__device__ int block_arg_min(const PitchLds &L, int toKeep, int lo, int hi)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    MinIdx m; m.v = L.xs[toKeep + lo]; m.i = lo;          // ext = sample at idxStart, always read
+    for (int i = lo + 1 + tid; i < hi; i += nt) {
+        MinIdx o; o.v = L.xs[toKeep + i]; o.i = i;
+        m = min_first(m, o);
+    }
+    m = wave_min_first(m);
+    if ((tid & 63) == 0) L.part[tid >> 6] = m;
+    __syncthreads();
+    MinIdx b = L.part[0];
+    for (int w = 1; w < (nt >> 6); w++) b = min_first(b, L.part[w]);
+    __syncthreads();
+    return b.i;
+}
+
+__device__ __forceinline__ int marks_back(const int *v, int n, unsigned long long *ub)
+{
+    // std::vector::back(); empty -> the reference reads the word before the heap block (0 on glibc)
+    if (n > 0) return v[n - 1];
+    if (threadIdx.x == 0) atomicAdd(&ub[2], 1ULL);
+    return 0;
+}
+
+// PitchProcess::pitchMarks (PitchProcess.cpp:455-567).  All threads walk the control flow (it is
+// uniform); thread 0 owns the writes to the mark arrays; arg-min searches use the whole group.
+__device__ void pitch_marks(const VpGeom &g, const PitchLds &L, unsigned long long *ub)
+{
+    VpPitchState *st = L.st;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        for (int i = 0; i < st->nAn; i++) st->prevAnMarks[i] = st->anMarks[i] - g.H;   // prevAnMarks = anMarks; -= hop
+        st->nPrevAn = st->nAn;
+        int ov = 0;
+        for (int i = 0; i < st->nAn; i++) if (st->prevAnMarks[i] >= 0) ov++;
+        st->nAnMarksOv = ov;
+        st->nAn = 0;
+    }
+    __syncthreads();
+    const int nPrev = st->nPrevAn, nOv = st->nAnMarksOv;
+    const double pitch = st->pitch, prevPitch = st->prevPitch;
+    const int period = st->period, prevPeriod = st->prevPeriod, pvp = st->prevVoicedPeriod;
+    int n = 0, front = 0, back = 0;                  // uniform mirrors of anMarks.size()/front()/back()
+    int *an = st->anMarks;
+    __syncthreads();
+
+#define PUSH_BACK(val) do { int _v = (val); if (tid == 0) { if (n < VP_MARKS) an[n] = _v; if (n + 1 > 20) atomicAdd(&ub[4], 1ULL); } \
+                            if (n == 0) front = _v; back = _v; if (n < VP_MARKS) n++; } while (0)
+#define PUSH_FRONT(val) do { int _v = (val); if (tid == 0) { int _k = n < VP_MARKS ? n : VP_MARKS - 1; \
+                            for (int _i = _k; _i > 0; _i--) an[_i] = an[_i - 1]; an[0] = _v; if (n + 1 > 20) atomicAdd(&ub[4], 1ULL); } \
+                            front = _v; if (n < VP_MARKS) n++; } while (0)
+
+    if (pitch > 1) {
+        const int sw_c = (int)floor(g.delta * period);
+        const int sw_f = (int)ceil((2.0 - g.delta) * period);
+        bool searchLeft = false;
+        int t;
+        if (prevPitch > 1) {
+            if (nOv == 0) {
+                int lastMark = marks_back(st->prevAnMarks, nPrev, ub);
+                int l_lim = max(lastMark + min(sw_c, (int)floor(g.delta * min(prevPeriod, period))), 0);
+                int r_lim = min(lastMark + max(sw_f, (int)ceil((2 - g.delta) * max(prevPeriod, period))), g.F);
+                t = block_arg_min(L, g.toKeep, l_lim, r_lim);
+            } else
+                t = st->prevAnMarks[nPrev - nOv];
+        } else {
+            searchLeft = true;
+            t = block_arg_min(L, g.toKeep, 0, g.F);
+        }
+        PUSH_BACK(t);
+        while (back + sw_c < g.F) {                                         // :505-519
+            if (back + sw_f < g.F) {
+                int m = block_arg_min(L, g.toKeep, back + sw_c, back + sw_f);
+                PUSH_BACK(m);
+            } else {
+                if (back + period < g.F) {
+                    int m = block_arg_min(L, g.toKeep, back + sw_c, g.F);
+                    PUSH_BACK(m);
+                }
+                break;
+            }
+        }
+        if (searchLeft) {                                                    // :522-539
+            while (front - sw_c > 0) {
+                if (front - sw_f >= 0) {
+                    int m = block_arg_min(L, g.toKeep, front - sw_f, front - sw_c);
+                    PUSH_FRONT(m);
+                } else {
+                    if (front - period >= 0) {
+                        int m = block_arg_min(L, g.toKeep, 0, front - sw_c);
+                        PUSH_FRONT(m);
+                    }
+                    break;
+                }
+            }
+        }
+    } else {
+        if (nPrev != 0) {                                                    // :545-565
+            if (nOv > 0) {
+                for (int i = 0; i < nOv; i++) PUSH_BACK(st->prevAnMarks[nPrev - nOv + i]);
+            } else
+                PUSH_BACK(marks_back(st->prevAnMarks, nPrev, ub) + pvp);
+            if (pvp > 0)
+                while (back + pvp < g.F) PUSH_BACK(back + pvp);
+        }
+    }
+#undef PUSH_BACK
+#undef PUSH_FRONT
+    __syncthreads();
+    if (tid == 0) st->nAn = n;
+    __syncthreads();
+}
+
+// Notes::getClosestFreq (Notes.cpp:79-110) on the precomputed table of `key`.
+__device__ double notes_closest(const double *freq, int size, double pitch)
+{
+    int lo = 0, hi = size;
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        if (freq[mid] < pitch) lo = mid + 1; else hi = mid;
+    }
+    int idx = lo;
+    if (idx > 0) {
+        if (fabs(freq[idx] - pitch) <= fabs(freq[idx - 1] - pitch)) return freq[idx];   // may read the popped slot
+        return freq[idx - 1];
+    }
+    return freq[idx];
+}
+
+// PitchProcess::placeStMarks (PitchProcess.cpp:573-658), one lane.
+__device__ void place_st_marks(const VpGeom &g, const VpCall &c, const VpDev &d, VpPitchState *st)
+{
+    unsigned long long *ub = d.ub;
+    for (int i = 0; i < st->nSt; i++) st->prevStMarks[i] = st->stMarks[i] - g.H;
+    st->nPrevSt = st->nSt;
+    st->nSt = 0;
+    st->nStMarksOv = 0;
+    if (st->nAn == 0) return;
+    int nOv = 0;
+    for (int i = 0; i < st->nPrevSt; i++) if (st->prevStMarks[i] >= 0) nOv++;
+    st->nStMarksOv = nOv;
+    st->prevClosestFreq = st->closestFreq;
+    if (st->pitch > 1) {
+        st->closestFreq = notes_closest(d.notes + (size_t)c.key * VP_NOTES_STRIDE, d.notesN[c.key], st->pitch);
+        st->beta = st->closestFreq / st->pitch;
+        st->periodNew = (int)round(st->period / st->beta);
+    } else {
+        st->closestFreq = 0;
+        st->periodNew = st->prevVoicedPeriod;
+    }
+    if (st->periodNew <= 0) return;                 // the reference asserts (:604-608)
+    const int nPrev = st->nPrevSt;
+    const int periodNew = st->periodNew;
+    int firstMark;
+    if (st->pitch > 1) {
+        if (st->prevPitch > 1) {
+            if (nOv > 0)
+                firstMark = st->prevStMarks[nPrev - nOv];
+            else {
+                int b = marks_back(st->prevStMarks, nPrev, ub);
+                firstMark = (b + periodNew >= 0) ? b + periodNew : st->anMarks[0];
+            }
+        } else
+            firstMark = st->anMarks[0];
+    } else {
+        if (nPrev == 0) return;
+        if (nOv > 0)
+            firstMark = st->prevStMarks[nPrev - nOv];
+        else {
+            int b = st->prevStMarks[nPrev - 1];
+            int n = 1;
+            while (b + n * periodNew < 0) n += 1;
+            firstMark = b + n * periodNew;
+        }
+    }
+    int n = 0;
+    st->stMarks[n++] = firstMark;
+    while (st->stMarks[n - 1] + periodNew < g.F) {
+        int v = st->stMarks[n - 1] + periodNew;
+        if (n < VP_MARKS) st->stMarks[n] = v;
+        if (n + 1 > 20) atomicAdd(&ub[4], 1ULL);
+        if (n < VP_MARKS) n++; else break;
+    }
+    st->nSt = n;
+}
+
+// PitchProcess::getClosestAnMarkIdx (PitchProcess.cpp:788-831); uniform, read-only.
+__device__ int closest_an_mark_idx(const VpGeom &g, const VpPitchState *st, int stMark, int T, int nChunk,
+                                   int pS, unsigned long long *ub)
+{
+    const int *an = st->anMarks;
+    const int nAn = st->nAn;
+    int lo = 0, hi = nAn;
+    while (lo < hi) {
+        int mid = lo + (hi - lo) / 2;
+        if (an[mid] < stMark) lo = mid + 1; else hi = mid;
+    }
+    const int idx = lo;
+    const int avail = g.bufferIdxMax - pS;
+    const int sh = nChunk * g.C;
+    if (idx > 0 && idx < nAn) {
+        if (abs(an[idx] - stMark) <= abs(an[idx - 1] - stMark) && an[idx] + T - sh < avail) return idx;
+        if (an[idx - 1] + T - sh < avail) return idx - 1;
+        if (idx - 2 > 0) return idx - 2;
+        return -st->nAnMarksOv - 1;                                         // :812 -> Q3
+    }
+    if (idx == 0) return 0;
+    if (threadIdx.x == 0) atomicAdd(&ub[0], 1ULL);                          // Q2: anMarks[size]
+    int stale = idx < VP_MARKS ? an[idx] : 0;
+    if (stale + T - sh < avail) return idx - 1;
+    if (idx - 2 >= 0) return idx - 2;
+    return idx - 1;
+}
+
+// PitchProcess::psola (PitchProcess.cpp:665-741) + interp (:842-870): grains in order, the output
+// samples of one grain in parallel.
+__device__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS)
+{
+    VpPitchState *st = L.st;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
+    const int nG = 2 * T + 1;
+    const double *hw = d.hannTab + d.hannOff[T];
+    const double beta = st->beta;
+    const int nSt = st->nSt;
+    int smi = st->stMarkIdx;
+    __syncthreads();
+    while (smi < nSt) {
+        const int stMark = st->stMarks[smi];
+        if (stMark - T >= (nChunk + 1) * g.C) break;                        // :685
+        int clIdx = closest_an_mark_idx(g, st, stMark, T, nChunk, pS, d.ub);
+        int clAnMark;
+        if (clIdx >= 0)
+            clAnMark = st->anMarks[clIdx];
+        else {                                                               // Q3
+            int j = st->nPrevAn - clIdx;
+            if (tid == 0) atomicAdd(&d.ub[1], 1ULL);
+            clAnMark = (j >= 0 && j < VP_MARKS) ? st->prevAnMarks[j] : 0;
+        }
+        const bool first = (smi == 0);
+        const bool last = (smi == nSt - 1);
+        const int srcBase = g.toKeep + clAnMark - T;
+        const double dSt = (double)stMark;
+        const double x0 = dSt + (double)(-T) / beta;                        // xInterp[0]
+        const double xN = dSt + (double)(T) / beta;                         // xInterp.back()
+        const int startIdx = max((int)floor(x0), 0);
+        const int stopIdx = min((int)ceil(xN), g.F);
+        for (int i = startIdx + tid; i < stopIdx; i += nt) {
+            const double di = (double)i;
+            if (di >= x0 && di <= xN) {
+                // std::lower_bound on the strictly increasing x[j] = stMark + (j - T)/beta
+                int j = (int)ceil((di - dSt) * beta) + T;
+                j = max(0, min(j, nG - 1));
+                while (j > 0 && dSt + (double)(j - 1 - T) / beta >= di) j--;
+                while (j < nG - 1 && dSt + (double)(j - T) / beta < di) j++;
+                auto ys = [&](int jj) -> double {
+                    int src = srcBase + jj;
+                    double e = (src >= 0 && src < g.eLen) ? L.eF[src] : 0.0;
+                    bool windowed = first ? (jj >= T) : (last ? (jj < T) : true);      // :696-731
+                    return windowed ? e * hw[jj] : e;
+                };
+                double value;
+                if (j > 0) {
+                    double xa = dSt + (double)(j - 1 - T) / beta, xb = dSt + (double)(j - T) / beta;
+                    double ya = ys(j - 1), yb = ys(j);
+                    value = ya + (yb - ya) / (xb - xa) * (di - xa);
+                } else
+                    value = ys(0);
+                L.oE[i] += value;
+            }
+        }
+        __syncthreads();
+        smi++;
+    }
+    __syncthreads();
+    if (tid == 0) st->stMarkIdx = smi;
+    __syncthreads();
+}
+
+__device__ void pitch_iir(const VpGeom &g, const PitchLds &L, int nChunk)
+{
+    // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion, one lane
+    if (threadIdx.x == 0) {
+        const int shift = nChunk * g.C, order = g.orderPitch;
+        const double *a = L.st->a;
+        for (int i = 0; i < g.C; i++) {
+            double y = L.oE[i + shift];
+            int kmax = min(order, i + shift);
+            for (int k = 1; k <= kmax; k++) y -= L.yF[i + shift - k] * a[k];
+            L.yF[i + shift] = y;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+                                  int nChunk, int pS, int s)
+{
+    // PitchProcess::fillOutputBuffer (PitchProcess.cpp:328-342)
+    double *acc = d.outAcc + (size_t)s * g.outSize;
+    for (int i = threadIdx.x; i < g.C; i += blockDim.x) {
+        int pos = (c.outCounter + pS + i) % g.outSize;
+        acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
+    }
+    __syncthreads();
+}
+
+__device__ void pitch_chunk_cont(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+                                 int nChunk, int pS, int s)
+{
+    // PitchProcess::processChunkCont (PitchProcess.cpp:253-271)
+    if (L.st->nAn == 0) return;
+    const int order = g.orderPitch;
+    const double *a = L.st->a;
+    for (int i = threadIdx.x; i < g.C; i += blockDim.x) {                   // filterFIR(F-C, C, toKeep+F+(n-1)C)
+        int xi = g.toKeep + g.F - g.C + i;
+        double e = a[0] * L.xs[xi];
+        for (int k = 1; k <= order; k++) e += L.xs[xi - k] * a[k];
+        L.eF[g.toKeep + g.F + (nChunk - 1) * g.C + i] = e;
+    }
+    __syncthreads();
+    psola(g, d, L, nChunk, pS);
+    pitch_iir(g, L, nChunk);
+    pitch_fill_output(g, c, d, L, nChunk, pS, s);
+}
+
+__device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+                                  int pS, int s)
+{
+    // PitchProcess::processChunkStart (PitchProcess.cpp:203-247)
+    VpPitchState *st = L.st;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (!d.gate[s * 2 + 0]) {                                               // :208-214
+        __syncthreads();
+        if (tid == 0) { st->nAn = 0; st->prevPitch = 0; st->gateOpen = 0; }
+        __syncthreads();
+        return;
+    }
+    for (int i = tid; i < g.eLen; i += nt) L.eF[i] = 0.0;                  // :216-218
+    for (int i = tid; i < g.F; i += nt) { L.oE[i] = 0.0; L.yF[i] = 0.0; }
+    if (tid == 0) {                                                          // yin() state roll, :415-425
+        st->gateOpen = 1;
+        st->prevPeriod = st->period;
+        st->prevPitch = st->pitch;
+        if (st->pitch > 1) { st->prevVoicedPeriod = st->period; st->prevVoicedPitch = st->pitch; }
+        st->pitch = 0; st->period = 0;
+        L.ishare[0] = INT_MAX;
+    }
+    // computeYinTemp (PitchProcess.cpp:350-403): one lane per lag k, sum over i in order.
+    {
+        const int base = g.toKeep - g.tauMax;
+        for (int k = tid; k < g.tauMax; k += nt) {
+            double accv = 0.0;
+            const double *xa = L.xs + base, *xb = L.xs + base + k;
+#pragma unroll 4
+            for (int i = 0; i < g.F; i++) {
+                double df = xa[i] - xb[i];
+                accv += df * df;
+            }
+            L.dY[k] = accv;
+        }
+    }
+    // LPC autocorrelation of the frame (rectangular window: the products with 1.0 are exact),
+    // LPC.cpp:44-97; independent of the pitch decisions, so it is done in the same phase.
+    // Its result is only used when analysis marks exist (:230-233).
+    {
+        const int order = g.orderPitch;
+        const double *x = L.xs + g.toKeep;
+        for (int m = nt - 1 - tid; m <= order && m >= 0; m += nt) {       // highest threads: they have no YIN lag
+            double sum = 0.0;
+            for (int n = 0; n < g.F - m; n++) sum += x[n] * x[n + m];
+            L.r[m] = sum / (double)g.F;
+        }
+        if (order >= nt) { /* orders are <= 100 < blockDim */ }
+    }
+    __syncthreads();
+    if (tid == 0) {                                                          // :395-402 running sum, in order
+        L.dY[0] = 1.0;
+        double tmp = 0;
+        for (int k = 1; k < g.tauMax; k++) { tmp += L.dY[k]; L.cum[k] = tmp; }
+        L.dY[g.tauMax] = 0.0;                                                // guard slot (see oracle)
+    }
+    __syncthreads();
+    for (int k = 1 + tid; k < g.tauMax; k += nt) L.dY[k] *= (double)k / L.cum[k];
+    __syncthreads();
+    for (int k = g.tau0 + tid; k < g.tauMax; k += nt)                      // first tau with d < tol (:431-433)
+        if (L.dY[k] < g.yinTol) atomicMin(&L.ishare[0], k);
+    __syncthreads();
+    if (tid == 0) {
+        int tau = L.ishare[0];
+        if (tau < g.tauMax) {
+            while (L.dY[tau + 1] < L.dY[tau]) {                              // :435-440
+                tau += 1;
+                if (tau + 1 >= g.tauMax) break;
+            }
+            if (tau >= g.tauMax) atomicAdd(&d.ub[3], 1ULL);
+            st->pitch = g.fs / tau;
+            st->period = tau;
+        }
+    }
+    __syncthreads();
+    pitch_marks(g, L, d.ub);
+    if (tid == 0) place_st_marks(g, c, d, st);
+    __syncthreads();
+    if (st->nAn != 0) {
+        if (tid == 0) levinson_durbin(L.r, st->a, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        __syncthreads();
+        const int order = g.orderPitch;
+        const double *a = st->a;
+        for (int j = tid; j < g.toKeep + g.F; j += nt) {                    // filterFIR(-toKeep, toKeep+F, 0) :280-302
+            double e = a[0] * L.xs[j];
+            int kmax = min(order, j);
+            for (int k = 1; k <= kmax; k++) e += L.xs[j - k] * a[k];
+            L.eF[j] = e;
+        }
+        if (tid == 0) st->stMarkIdx = 0;
+        __syncthreads();
+        psola(g, d, L, 0, pS);
+        pitch_iir(g, L, 0);
+    }
+    pitch_fill_output(g, c, d, L, 0, pS, s);
+}
+
+__global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
+{
+    extern __shared__ double smem[];
+    const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    PitchLds L;
+    L.xs = smem;
+    L.eF = L.xs + (g.toKeep + g.F);
+    L.oE = L.eF + g.eLen;
+    L.yF = L.oE + g.F;
+    L.dY = L.yF + g.F;
+    L.cum = L.dY + (g.tauMax + 1);
+    L.r = L.cum + (g.tauMax + 1);
+    L.aPrev = L.r + (VP_ORDER_MAX + 1);
+    L.part = (MinIdx *)(L.aPrev + (VP_ORDER_MAX + 1));
+    L.st = (VpPitchState *)(L.part + 8);
+    L.ishare = (int *)(L.st + 1);
+
+    {   // state in
+        const int *src = (const int *)(d.pitch + s);
+        int *dst = (int *)L.st;
+        for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
+    }
+    __syncthreads();
+    const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
+    if (frameLive0) {
+        const double *ge = d.eFrame + (size_t)s * g.eLen, *go = d.outEFrame + (size_t)s * g.F, *gy = d.yFrame + (size_t)s * g.F;
+        for (int i = tid; i < g.eLen; i += nt) L.eF[i] = ge[i];
+        for (int i = tid; i < g.F; i += nt) { L.oE[i] = go[i]; L.yF[i] = gy[i]; }
+    }
+    __syncthreads();
+
+    const float *vr = d.voiceRing + (size_t)s * g.inSize;
+    int pS = c.pStart, nChunk = c.nChunk0;
+    for (int step = 0; step < c.nSteps; step++) {
+        // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double
+        for (int j = tid; j < g.toKeep + g.F; j += nt)
+            L.xs[j] = (double)vr[ring_pos(c.currCounter, pS - g.toKeep + j, g.inSize)];
+        __syncthreads();
+        if (nChunk % g.cpf == g.cpf - 1) {                                  // :171-178
+            pitch_chunk_cont(g, c, d, L, nChunk, pS, s);
+            __syncthreads();
+            nChunk = 0;
+            pitch_chunk_start(g, c, d, L, pS, s);
+            nChunk += 1;
+            nChunk %= g.cpf;
+        } else if (nChunk == 0) {
+            pitch_chunk_start(g, c, d, L, pS, s);
+            nChunk += 1;
+        } else {
+            pitch_chunk_cont(g, c, d, L, nChunk, pS, s);
+            nChunk += 1;
+        }
+        __syncthreads();
+        pS += g.C;
+    }
+
+    {   // state out
+        int *dst = (int *)(d.pitch + s);
+        const int *src = (const int *)L.st;
+        for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
+    }
+    if (nChunk != 0 && L.st->nAn != 0) {
+        double *ge = d.eFrame + (size_t)s * g.eLen, *go = d.outEFrame + (size_t)s * g.F, *gy = d.yFrame + (size_t)s * g.F;
+        for (int i = tid; i < g.eLen; i += nt) ge[i] = L.eF[i];
+        for (int i = tid; i < g.F; i += nt) { go[i] = L.oE[i]; gy[i] = L.yF[i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: emit.  addDryVoice / addSynth (MyBuffer.cpp:309-448) + fillOutputBuffer + clearOutput
+// (MyBuffer.cpp:113-133, 218-228).  out[ch] = float(((acc + dry) + synth_ch)); the consumed region of
+// the accumulator is zeroed.
+__global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out)
+{
+    const int s = blockIdx.x;
+    const float *vr = d.voiceRing + (size_t)s * g.inSize;
+    const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
+    const float *sr1 = sr0 + g.inSize;
+    double *acc = d.outAcc + (size_t)s * g.outSize;
+    float *o = out + (size_t)s * (c.inplace ? 3 : 2) * g.N;
+    for (int i = threadIdx.x; i < g.N; i += blockDim.x) {
+        int pos = (c.outCounter + i) % g.outSize;
+        int pin = (c.currCounter + i) % g.inSize;
+        double v = acc[pos];
+        if (c.dryOn) v += (double)vr[pin] * c.gainVoice;
+        double l = v, r = v;
+        if (c.synthOn) { l += (double)sr0[pin] * c.gainSynth; r += (double)sr1[pin] * c.gainSynth; }
+        o[i] = (float)l;
+        o[g.N + i] = (float)r;
+        if (c.inplace) o[2 * g.N + i] = 0.0f;
+        acc[pos] = 0.0;
+    }
+}

@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's plugin surface over the C ABI (include/vp_amd.h).
+
+`BatchVocoderProcessor` plays the role of `VocoderAudioProcessor` (PluginProcessor.h:24-80) for a
+batch of independent streams on one MI355X: the same ten parameters (PluginProcessor.cpp:37-73),
+`prepareToPlay(sampleRate, samplesPerBlock)` (:144) and `processBlock(buffer)` (:203) on planar
+float32 buffers `[stream][channel][sample]`.  Everything below the class is ctypes plumbing; the
+compute lives in libvp_amd.so (HIP kernels).  There is no CPU fallback: if the shared library is
+missing or no GPU is present the constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvp_amd.so")
+
+PARAM_IDS = ("gainPitch", "gainVoice", "gainSynth", "gainVoc", "lpcVoice", "lpcPitch",
+             "lpcSynth", "keyPitch", "pitchBool", "vocBool")
+KEYS = ("A", "A#", "B", "C", "C#", "D", "D#", "E", "F", "F#", "G", "G#", "Chrom")   # PluginProcessor.cpp:64
+GEOM_KEYS = ("N", "F", "H", "C", "W", "h", "toKeep", "latency", "inSize", "outSize", "tauMax", "chunksPerFrame")
+KERNEL_SLOTS = 4
+MARK_CAP = 64
+
+
+class VpParams(C.Structure):
+    _fields_ = [("gainPitch", C.c_float), ("gainVoice", C.c_float), ("gainSynth", C.c_float), ("gainVoc", C.c_float),
+                ("lpcVoice", C.c_int), ("lpcPitch", C.c_int), ("lpcSynth", C.c_int), ("keyPitch", C.c_int),
+                ("pitchBool", C.c_int), ("vocBool", C.c_int)]
+
+
+class VpPitchState(C.Structure):
+    _fields_ = [("period", C.c_int), ("prevPeriod", C.c_int), ("prevVoicedPeriod", C.c_int), ("periodNew", C.c_int),
+                ("nAn", C.c_int), ("nSt", C.c_int), ("stMarkIdx", C.c_int), ("gateOpen", C.c_int),
+                ("pitch", C.c_double), ("prevPitch", C.c_double), ("beta", C.c_double), ("closestFreq", C.c_double),
+                ("anMarks", C.c_int * MARK_CAP), ("stMarks", C.c_int * MARK_CAP), ("a", C.c_double * 101)]
+
+
+class VpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvp_amd error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvp_amd.so (built by vocoderproject_amd.build). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -m vocoderproject_amd.build` "
+                                "(needs hipcc); this package has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    fp = C.c_void_p      # float* passed as integer addresses (host numpy or device data_ptr)
+    L.vp_abi_version.restype = C.c_int
+    L.vp_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vp_destroy.argtypes = [vp]
+    L.vp_set_params.argtypes = [vp, C.POINTER(VpParams)]
+    L.vp_get_params.argtypes = [vp, C.POINTER(VpParams)]
+    L.vp_default_params.argtypes = [C.POINTER(VpParams)]
+    L.vp_default_params.restype = None
+    L.vp_prepare_to_play.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    L.vp_prepare_explicit.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.vp_process_block.argtypes = [vp, fp, fp]
+    L.vp_process_block_inplace.argtypes = [vp, fp]
+    L.vp_process_block_device.argtypes = [vp, fp, fp, C.c_void_p]
+    L.vp_get_latency.argtypes = [vp]
+    L.vp_get_geometry.argtypes = [vp, C.POINTER(C.c_int)]
+    L.vp_get_num_streams.argtypes = [vp]
+    L.vp_read_pitch_state.argtypes = [vp, C.c_int, C.POINTER(VpPitchState)]
+    L.vp_synchronize.argtypes = [vp]
+    L.vp_profile_enable.argtypes = [vp, C.c_int]
+    L.vp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]
+    L.vp_kernel_slot_name.argtypes = [C.c_int]
+    L.vp_kernel_slot_name.restype = C.c_char_p
+    L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
+    L.vp_error_string.argtypes = [C.c_int]
+    L.vp_error_string.restype = C.c_char_p
+    L.vp_last_error.argtypes = [vp]
+    L.vp_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+class BatchVocoderProcessor:
+    """A batch of `VocoderAudioProcessor` instances on one GPU (one per stream)."""
+
+    def __init__(self, device=0, **params):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.vp_create(int(device), C.byref(h))
+        if rc:
+            raise VpError(rc, self.L.vp_error_string(rc).decode())
+        self.h = h
+        self.device = device
+        self._p = VpParams()
+        self.L.vp_default_params(C.byref(self._p))
+        self.n_streams = 0
+        self.N = 0
+        for k, v in params.items():
+            self.setParameter(k, v)
+
+    # ---- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise VpError(rc, f"{self.L.vp_error_string(rc).decode()} ({self.L.vp_last_error(self.h).decode()})")
+
+    # ---- parameters (treeState) --------------------------------------------------------------------
+    def setParameter(self, pid, value):
+        if pid not in PARAM_IDS:
+            raise KeyError(pid)
+        old = getattr(self._p, pid)
+        setattr(self._p, pid, type(old)(value))
+        rc = self.L.vp_set_params(self.h, C.byref(self._p))
+        if rc:
+            setattr(self._p, pid, old)
+            self._chk(rc)
+
+    def getParameter(self, pid):
+        return getattr(self._p, pid)
+
+    # ---- prepareToPlay -----------------------------------------------------------------------------
+    def prepareToPlay(self, sampleRate, samplesPerBlock, nStreams=1):
+        self._chk(self.L.vp_prepare_to_play(self.h, float(sampleRate), int(samplesPerBlock), int(nStreams)))
+        self.n_streams, self.N = int(nStreams), int(samplesPerBlock)
+
+    def prepareExplicit(self, sampleRate, samplesPerBlock, nStreams, frameLenPitch, hopPitch, wlenVoc, hopVoc):
+        self._chk(self.L.vp_prepare_explicit(self.h, float(sampleRate), int(samplesPerBlock), int(nStreams),
+                                             int(frameLenPitch), int(hopPitch), int(wlenVoc), int(hopVoc)))
+        self.n_streams, self.N = int(nStreams), int(samplesPerBlock)
+
+    def getLatencySamples(self):
+        rc = self.L.vp_get_latency(self.h)
+        if rc < 0:
+            self._chk(rc)
+        return rc
+
+    def geometry(self):
+        g = (C.c_int * 12)()
+        self._chk(self.L.vp_get_geometry(self.h, g))
+        return dict(zip(GEOM_KEYS, list(g)))
+
+    # ---- processBlock ---------------------------------------------------------------------------------
+    def processBlock(self, buffer):
+        """In place, like the reference: float32 numpy [S][3][N]; on return ch0/ch1 = out L/R, ch2 = 0."""
+        assert isinstance(buffer, np.ndarray) and buffer.dtype == np.float32 and buffer.flags.c_contiguous
+        assert buffer.shape == (self.n_streams, 3, self.N), buffer.shape
+        self._chk(self.L.vp_process_block_inplace(self.h, buffer.ctypes.data))
+
+    def process(self, x):
+        """Host convenience: float32 numpy [S][3][N] -> new float32 [S][2][N]."""
+        assert x.dtype == np.float32 and x.flags.c_contiguous and x.shape == (self.n_streams, 3, self.N)
+        out = np.empty((self.n_streams, 2, self.N), np.float32)
+        self._chk(self.L.vp_process_block(self.h, x.ctypes.data, out.ctypes.data))
+        return out
+
+    def process_device(self, d_in, d_out, stream=None):
+        """Device-resident, asynchronous: torch CUDA(HIP) float32 tensors [S][3][N] -> [S][2][N]."""
+        assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()
+        assert tuple(d_in.shape) == (self.n_streams, 3, self.N) and tuple(d_out.shape) == (self.n_streams, 2, self.N)
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        self._chk(self.L.vp_process_block_device(self.h, d_in.data_ptr(), d_out.data_ptr(), C.c_void_p(stream)))
+
+    def run(self, x):
+        """x: float32 numpy [S][3][T], T a multiple of N -> float32 [S][2][T] (block by block)."""
+        S, _, T = x.shape
+        assert S == self.n_streams and T % self.N == 0
+        out = np.empty((S, 2, T), np.float32)
+        for b in range(T // self.N):
+            blk = np.ascontiguousarray(x[:, :, b * self.N:(b + 1) * self.N])
+            out[:, :, b * self.N:(b + 1) * self.N] = self.process(blk)
+        return out
+
+    # ---- introspection ------------------------------------------------------------------------------------
+    def synchronize(self):
+        self._chk(self.L.vp_synchronize(self.h))
+
+    def pitch_state(self, stream):
+        st = VpPitchState()
+        self._chk(self.L.vp_read_pitch_state(self.h, int(stream), C.byref(st)))
+        return dict(period=st.period, prevPeriod=st.prevPeriod, prevVoicedPeriod=st.prevVoicedPeriod,
+                    periodNew=st.periodNew, pitch=st.pitch, prevPitch=st.prevPitch, beta=st.beta,
+                    closestFreq=st.closestFreq, gateOpen=st.gateOpen, stMarkIdx=st.stMarkIdx,
+                    anMarks=list(st.anMarks[:st.nAn]), stMarks=list(st.stMarks[:st.nSt]), a=np.array(st.a[:]))
+
+    def ub_counters(self):
+        c = (C.c_long * 5)()
+        self._chk(self.L.vp_read_ub_counters(self.h, c))
+        return list(c)
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.vp_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * KERNEL_SLOTS)()
+        n = (C.c_long * KERNEL_SLOTS)()
+        self._chk(self.L.vp_profile_read(self.h, ms, n, int(bool(reset))))
+        return {self.L.vp_kernel_slot_name(i).decode(): (ms[i], n[i]) for i in range(KERNEL_SLOTS)}
