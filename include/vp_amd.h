@@ -132,6 +132,10 @@ const char *vp_kernel_slot_name(int slot);
  * same meaning as the oracle's counters. Synchronises. */
 int vp_read_ub_counters(vp_handle *h, long out[5]);
 
+/* Diagnostic build (-DVP_STAMPS) only: per-phase timers (100 MHz ticks) of workgroup 0; all zero in
+ * the product build. */
+int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
+
 const char *vp_error_string(int code);
 const char *vp_last_error(const vp_handle *h);
 int vp_abi_version(void);

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does a kernel spend its time?  Builds/loads the -DVP_STAMPS library and prints,
+per phase, the microseconds workgroup 0 spent (100 MHz wall clock) averaged per step.
+
+    VP_AMD_LIB=vocoderproject_amd/libvp_amd_stamps.so python tools/phase_stamps.py [--mode both] [--steps 50]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("VP_AMD_LIB", os.path.join(ROOT, "vocoderproject_amd", "libvp_amd_stamps.so"))
+
+PHASES = {0: "pitch: load xs", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/normalise/pick", 3: "pitch: an marks",
+          4: "pitch: st marks", 5: "pitch: levinson", 6: "pitch: FIR start", 7: "pitch: psola", 8: "pitch: IIR",
+          9: "pitch: fill output", 10: "pitch: FIR cont", 11: "pitch: state out",
+          16: "voc: load", 17: "voc: autocorr", 18: "voc: levinson", 19: "voc: FIR", 20: "voc: energies",
+          21: "voc: gains", 22: "voc: IIR", 23: "voc: scale+OLA"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="both")
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--block", type=int, default=1024)
+    a = ap.parse_args()
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    from vocoderproject_amd.synth import make_streams
+    S, N = a.streams, a.block
+    p = BatchVocoderProcessor(pitchBool=int(a.mode != "voc"), vocBool=int(a.mode != "pitch"))
+    p.prepareToPlay(44100.0, N, S)
+    U = 16
+    x = make_streams(S, N * U, device="cuda").view(S, 3, U, N).permute(2, 0, 1, 3).contiguous()
+    y = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
+    for i in range(8):
+        p.process_device(x[i % U], y)
+    p.debug_stamps(reset=True)
+    for i in range(a.steps):
+        p.process_device(x[(8 + i) % U], y)
+    st = p.debug_stamps()
+    tot = sum(st)
+    print(f"mode={a.mode} S={S} N={N}: per-step microseconds of workgroup 0 (sum {tot / a.steps:.1f})")
+    for i, t in enumerate(st):
+        if t:
+            print(f"  {PHASES.get(i, i):32s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()

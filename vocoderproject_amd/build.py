@@ -31,19 +31,27 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+LIB_STAMPS = os.path.join(HERE, "libvp_amd_stamps.so")
+
+
+def build(force=False, verbose=False, stamps=False):
+    """stamps=True builds the DIAGNOSTIC library (in-kernel phase timers, -DVP_STAMPS) next to the
+    product one; it is only ever loaded through VP_AMD_LIB by tools/phase_stamps.py."""
+    lib = LIB_STAMPS if stamps else LIB
+    if not stamps and not force and not needs_build():
         return LIB
     cmd = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
            f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if stamps:
+        cmd.append("-DVP_STAMPS")
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-o", LIB]
+    cmd += ["-o", lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))

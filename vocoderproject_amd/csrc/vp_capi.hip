@@ -327,6 +327,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.yFrame, (size_t)S * F));
     RC(dev_alloc(h, &d.EeArr, (size_t)S * 20));
     RC(dev_alloc(h, &d.ub, (size_t)5));
+    RC(dev_alloc(h, &d.dbg, (size_t)64));
     RC(dev_upload(h, &d.vocWin, vocWin));
     RC(dev_upload(h, &d.pitchStWin, pitchSt));
     RC(dev_upload(h, &d.hannTab, hannTab));
@@ -563,5 +564,17 @@ extern "C" int vp_profile_read(vp_handle *h, double ms[VP_NUM_KERNEL_SLOTS], lon
     h->pending.clear();
     for (int i = 0; i < VP_NUM_KERNEL_SLOTS; i++) { ms[i] = h->profMs[i]; launches[i] = h->profN[i]; }
     if (reset) for (int i = 0; i < VP_NUM_KERNEL_SLOTS; i++) { h->profMs[i] = 0; h->profN[i] = 0; }
+    return VP_OK;
+}
+
+// Diagnostic (-DVP_STAMPS build only): per-phase 100 MHz ticks accumulated by workgroup 0.
+extern "C" int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset)
+{
+    if (!h || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->d.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->d.dbg, 0, 64 * sizeof(unsigned long long)));
     return VP_OK;
 }

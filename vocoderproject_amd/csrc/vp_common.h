@@ -68,6 +68,7 @@ struct VpDev {
     const double *notes;     // [13][VP_NOTES_STRIDE]
     const int *notesN;       // [13]
     unsigned long long *ub;  // [5]
+    unsigned long long *dbg; // [64] phase timers of the -DVP_STAMPS diagnostic build
 };
 
 // doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)

@@ -17,6 +17,19 @@
 
 #define WAVE 64
 
+// Diagnostic build only (-DVP_STAMPS): workgroup 0 / thread 0 accumulates, per phase id, the
+// 100 MHz wall-clock ticks spent since the previous stamp into d.dbg[id].  No stamp executes in
+// the product build.
+#ifdef VP_STAMPS
+__device__ unsigned long long vp_last_stamp;
+#define STAMP(D, ID) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long _t = wall_clock64(); \
+        (D).dbg[ID] += _t - vp_last_stamp; vp_last_stamp = _t; } } while (0)
+#define STAMP0(D) do { if (blockIdx.x == 0 && threadIdx.x == 0) vp_last_stamp = wall_clock64(); } while (0)
+#else
+#define STAMP(D, ID) do { } while (0)
+#define STAMP0(D) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 
@@ -140,6 +153,145 @@ __device__ void levinson_durbin(const double *r, double *a, double *aPrev, int o
     for (int i = 1; i < order + 1; i++) a[i] *= -1.;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-uniform broadcast of a double held by lane `src` (src is wave-uniform): two v_readlane_b32.
+__device__ __forceinline__ double bcast_f64(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// Levinson-Durbin (LPC.cpp:107-148) by ONE WAVEFRONT with the coefficient vector spread over the
+// lanes: lane l owns a[l] and a[64+l].  The two dot products of every order step are summed in the
+// reference's order (i = 1..p-1, left to right) by broadcasting the per-lane products one after
+// the other, so the result is bit-identical to the serial recursion; the products and the
+// coefficient update run lane-parallel.  All 64 lanes must call it (wave-uniform arguments).
+__device__ void levinson_wave(const double *r, double *a, int order, int aLen, double eps)
+{
+    const int lane = threadIdx.x & 63;
+    if (fabs(r[0]) < eps) {                        // :110-114 (floating abs intended)
+        for (int i = lane; i < aLen; i += WAVE) a[i] = (i == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double r0 = r[0];
+    double a0 = 0.0, a1 = 0.0;                      // a[lane], a[64+lane]
+    if (lane == 0) a0 = 1.0;
+    if (lane == 1) a0 = r[1] / r0;
+    const double rl0 = (lane <= order) ? r[lane] : 0.0;             // r[i] for i = lane
+    const double rl1 = (64 + lane <= order) ? r[64 + lane] : 0.0;   // r[i] for i = 64+lane
+    for (int p = 2; p < order + 1; p++) {
+        // per-lane products for i = lane and i = 64+lane (only 1 <= i < p are consumed)
+        const int i0 = lane, i1 = 64 + lane;
+        double q0 = (i0 >= 1 && i0 < p) ? r[p - i0] * a0 : 0.0;
+        double q1 = (i1 < p) ? r[p - i1] * a1 : 0.0;
+        double s0 = rl0 * a0, s1 = rl1 * a1;
+        double rho_a = 0.0, r_a = 0.0;
+        const int n0 = min(p, 64);
+        for (int i = 1; i < n0; i++) { rho_a += bcast_f64(q0, i); r_a += bcast_f64(s0, i); }
+        for (int i = 64; i < p; i++) { rho_a += bcast_f64(q1, i - 64); r_a += bcast_f64(s1, i - 64); }
+        const double k = (r[p] - rho_a) / (r0 - r_a);
+        // a[i] = aPrev[i] - k * aPrev[p - i], 1 <= i < p
+        int j0 = p - i0, j1 = p - i1;                               // partner indices
+        double p0lo = __shfl(a0, j0 & 63, WAVE), p0hi = __shfl(a1, j0 & 63, WAVE);
+        double p1lo = __shfl(a0, j1 & 63, WAVE), p1hi = __shfl(a1, j1 & 63, WAVE);
+        double n0v = a0, n1v = a1;
+        if (i0 >= 1 && i0 < p) n0v = a0 - k * ((j0 >= 64) ? p0hi : p0lo);
+        if (i1 < p) n1v = a1 - k * ((j1 >= 64) ? p1hi : p1lo);
+        if (i0 == p) n0v = k;
+        if (i1 == p) n1v = k;
+        a0 = n0v; a1 = n1v;
+    }
+    if (lane >= 1) a0 *= -1.;                       // :145-146 (entries beyond the order are 0 -> -0, never read)
+    a1 *= -1.;
+    if (lane <= order) a[lane] = a0;
+    if (64 + lane <= order) a[64 + lane] = a1;
+}
+
+// Left-to-right sum of e[i]^2, i = 0..n-1 (VocoderProcess.cpp:250), by one wavefront: lane l holds
+// the squares of i = 64 j + l; they are folded into the running sum in index order by broadcast.
+// All 64 lanes must call it; every lane returns the sum.
+__device__ double energy_wave(const double *e, int n)
+{
+    const int lane = threadIdx.x & 63;
+    double E = 0.0;
+    for (int j0 = 0; j0 < n; j0 += WAVE) {
+        const int i = j0 + lane;
+        const double v = (i < n) ? e[i] : 0.0;
+        const double sq = v * v;
+        const int m = min(WAVE, n - j0);
+        for (int l = 0; l < m; l++) E += bcast_f64(sq, l);
+    }
+    return E;
+}
+
+// Exact all-pole recursion y[i] = g*x[i] - sum_{k=1..order} y[i-k]*a[k], the sum taken in the
+// reference's order k = 1, 2, ... (VocoderProcess.cpp:277-286, PitchProcess.cpp:307-322), by ONE lane.
+// The chain of (order+1) dependent double operations per sample is irreducible without changing
+// the rounding, so the job here is to make every step cost one VALU issue: coefficients and the
+// last P outputs live in registers (static indices: four samples per trip, history shifted by
+// four), x/y stream through LDS.  hist[j] = y[-1-j] (j < order) or nullptr for a zero state;
+// taps beyond `order` are skipped in groups of four (a[] is zero-padded inside the last group:
+// subtracting 0*h is exact).  n must be a multiple of 4.
+template <int P>
+__device__ void iir_exact_lane(const double *x, double *y, int n, const double *aL, int order, const double *hist, double gmul)
+{
+    static_assert(P % 4 == 0, "P multiple of 4");
+    double a[P + 1], h[P + 4];
+#pragma unroll
+    for (int k = 1; k <= P; k++) a[k] = (k <= order) ? aL[k] : 0.0;
+#pragma unroll
+    for (int j = 0; j < P; j++) h[j] = (hist != nullptr && j < order) ? hist[j] : 0.0;
+    const int groups = (order + 3) >> 2;
+    for (int i = 0; i < n; i += 4) {
+        double yn[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+            double acc = gmul * x[i + s2];
+#pragma unroll
+            for (int gq = 0; gq < P / 4; gq++) {
+                if (gq < groups) {
+#pragma unroll
+                    for (int kk = 1; kk <= 4; kk++) {
+                        const int k = gq * 4 + kk;
+                        const double hv = (k <= s2) ? yn[s2 - k] : h[k - 1 - s2];
+                        acc -= hv * a[k];
+                    }
+                }
+            }
+            yn[s2] = acc;
+        }
+#pragma unroll
+        for (int j = P - 1; j >= 4; j--) h[j] = h[j - 4];
+        h[3] = yn[0]; h[2] = yn[1]; h[1] = yn[2]; h[0] = yn[3];
+        y[i] = yn[0]; y[i + 1] = yn[1]; y[i + 2] = yn[2]; y[i + 3] = yn[3];
+    }
+}
+
+// Generic (any order, any n) form of the same recursion with the history read back from y[]:
+// y must be preceded by its own past (y[-k] valid for k <= min(order, i0 + i)).
+__device__ void iir_exact_generic(const double *x, double *y, int n, const double *aL, int order, int i0, double gmul)
+{
+    for (int i = 0; i < n; i++) {
+        double acc = gmul * x[i];
+        const int kmax = min(order, i0 + i);
+        for (int k = 1; k <= kmax; k++) acc -= y[i - k] * aL[k];
+        y[i] = acc;
+    }
+}
+
+// Dispatch on the order (wave-uniform).  hist as in iir_exact_lane; i0 = number of valid past
+// outputs before y[0] (only used by the generic path).
+__device__ void iir_exact(const double *x, double *y, int n, const double *aL, int order, const double *hist, int i0, double gmul)
+{
+    if ((n & 3) == 0 && order <= 16) iir_exact_lane<16>(x, y, n, aL, order, hist, gmul);
+    else if ((n & 3) == 0 && order <= 32) iir_exact_lane<32>(x, y, n, aL, order, hist, gmul);
+    else if ((n & 3) == 0 && order <= 48) iir_exact_lane<48>(x, y, n, aL, order, hist, gmul);
+    else iir_exact_generic(x, y, n, aL, order, i0, gmul);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: vocoder.  VocoderProcess::process/processWindow (VocoderProcess.cpp:173-223), one workgroup
 // per stream, one wavefront per window, windows of a block taken in rounds of (waves per group).
@@ -175,6 +327,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
     const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     double *acc = d.outAcc + (size_t)s * g.outSize;
+    STAMP0(d);
     __syncthreads();
 
     for (int w0 = 0; w0 < c.nWin; w0 += nWaves) {
@@ -193,6 +346,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
             }
         }
         __syncthreads();
+        STAMP(d, 16);
 
         // biaisedAutoCorr (LPC.cpp:44-97) for voice lags 0..oV and synth lags 0..oS: one lane per
         // lag, each lag its own left-to-right sum over n.
@@ -210,10 +364,13 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
             }
         }
         __syncthreads();
-        if (active && lane < 2)                          // voice on lane 0, carrier on lane 1, in lockstep
-            levinson_durbin(lane == 0 ? rV : rS, lane == 0 ? aV : aS, lane == 0 ? aPV : aPS, lane == 0 ? oV : oS,
-                            lane == 0 ? VP_ORDER_MAX + 1 : VP_ORDER_MAX_SYNTH + 1, g.levEps);
+        STAMP(d, 17);
+        if (active) {                                    // whole wavefront, coefficient vector over the lanes
+            levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps);
+            levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps);
+        }
         __syncthreads();
+        STAMP(d, 18);
 
         // filterFIR (VocoderProcess.cpp:235-251): zero history left of the window.
         if (active) {
@@ -234,13 +391,13 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
             }
         }
         __syncthreads();
-        if (active && lane < 2) {                        // E += e[i]*e[i], left to right (:250)
-            const double *e = lane == 0 ? D : A;
-            double E = 0.0;
-            for (int i = 0; i < W; i++) E += e[i] * e[i];
-            roundE[lane * 8 + wave] = E;
+        STAMP(d, 19);
+        if (active) {                                    // E += e[i]*e[i], left to right (:250)
+            const double Ev = energy_wave(D, W), Es = energy_wave(A, W);
+            if (lane == 0) { roundE[wave] = Ev; roundE[8 + wave] = Es; }
         }
         __syncthreads();
+        STAMP(d, 20);
 
         // filterIIR part 1 (VocoderProcess.cpp:264-275): 10-deep energy histories, window by window.
         if (tid == 0) {
@@ -259,18 +416,12 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
             }
         }
         __syncthreads();
+        STAMP(d, 21);
 
         // filterIIR part 2 (:277-286): all-pole recursion, serial in i; one lane per window.
-        if (active && lane == 0) {
-            const double gg = gArr[wave];
-            for (int i = 0; i < W; i++) {
-                double o = gg * A[i];
-                int kmax = min(oV, i);
-                for (int k = 1; k <= kmax; k++) o -= B[i - k] * aV[k];
-                B[i] = o;
-            }
-        }
+        if (active && lane == 0) iir_exact(A, B, W, aV, oV, nullptr, 0, gArr[wave]);
         __syncthreads();
+        STAMP(d, 22);
         if (active)                                      // gainVoc * out[i] * stWindow[i] (:291-295)
             for (int i = lane; i < W; i += WAVE) B[i] = c.gainVoc * B[i] * win[i];
         __syncthreads();
@@ -295,6 +446,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
             }
         }
         __syncthreads();
+        STAMP(d, 23);
     }
     if (tid < 20) d.EeArr[(size_t)s * 20 + tid] = hist[tid];
 }
@@ -595,22 +747,23 @@ __device__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nC
     __syncthreads();
     if (tid == 0) st->stMarkIdx = smi;
     __syncthreads();
+    STAMP(d, 7);
 }
 
-__device__ void pitch_iir(const VpGeom &g, const PitchLds &L, int nChunk)
+__device__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk)
 {
     // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion, one lane
     if (threadIdx.x == 0) {
         const int shift = nChunk * g.C, order = g.orderPitch;
-        const double *a = L.st->a;
-        for (int i = 0; i < g.C; i++) {
-            double y = L.oE[i + shift];
-            int kmax = min(order, i + shift);
-            for (int k = 1; k <= kmax; k++) y -= L.yF[i + shift - k] * a[k];
-            L.yF[i + shift] = y;
-        }
+        // history y[shift-1-j]; the frame starts from a zero state (yFrame is zero-filled at the
+        // frame start, so reading it as history for shift > 0 is the same thing)
+        double *hist = L.cum;                           // yinTemp scratch is free here
+        const int nh = min(order, shift);
+        for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
+        iir_exact(L.oE + shift, L.yF + shift, g.C, L.st->a, order, hist, shift, 1.0);
     }
     __syncthreads();
+    STAMP(d, 8);
 }
 
 __device__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
@@ -623,6 +776,7 @@ __device__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev 
         acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
     }
     __syncthreads();
+    STAMP(d, 9);
 }
 
 __device__ void pitch_chunk_cont(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
@@ -639,8 +793,9 @@ __device__ void pitch_chunk_cont(const VpGeom &g, const VpCall &c, const VpDev &
         L.eF[g.toKeep + g.F + (nChunk - 1) * g.C + i] = e;
     }
     __syncthreads();
+    STAMP(d, 10);
     psola(g, d, L, nChunk, pS);
-    pitch_iir(g, L, nChunk);
+    pitch_iir(g, d, L, nChunk);
     pitch_fill_output(g, c, d, L, nChunk, pS, s);
 }
 
@@ -691,9 +846,9 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
             for (int n = 0; n < g.F - m; n++) sum += x[n] * x[n + m];
             L.r[m] = sum / (double)g.F;
         }
-        if (order >= nt) { /* orders are <= 100 < blockDim */ }
     }
     __syncthreads();
+    STAMP(d, 1);
     if (tid == 0) {                                                          // :395-402 running sum, in order
         L.dY[0] = 1.0;
         double tmp = 0;
@@ -719,12 +874,16 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
         }
     }
     __syncthreads();
+    STAMP(d, 2);
     pitch_marks(g, L, d.ub);
+    STAMP(d, 3);
     if (tid == 0) place_st_marks(g, c, d, st);
     __syncthreads();
+    STAMP(d, 4);
     if (st->nAn != 0) {
-        if (tid == 0) levinson_durbin(L.r, st->a, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        if (tid < WAVE) levinson_wave(L.r, st->a, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
         __syncthreads();
+        STAMP(d, 5);
         const int order = g.orderPitch;
         const double *a = st->a;
         for (int j = tid; j < g.toKeep + g.F; j += nt) {                    // filterFIR(-toKeep, toKeep+F, 0) :280-302
@@ -735,8 +894,9 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
         }
         if (tid == 0) st->stMarkIdx = 0;
         __syncthreads();
+        STAMP(d, 6);
         psola(g, d, L, 0, pS);
-        pitch_iir(g, L, 0);
+        pitch_iir(g, d, L, 0);
     }
     pitch_fill_output(g, c, d, L, 0, pS, s);
 }
@@ -763,6 +923,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
         int *dst = (int *)L.st;
         for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
     }
+    STAMP0(d);
     __syncthreads();
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
     if (frameLive0) {
@@ -779,6 +940,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
         for (int j = tid; j < g.toKeep + g.F; j += nt)
             L.xs[j] = (double)vr[ring_pos(c.currCounter, pS - g.toKeep + j, g.inSize)];
         __syncthreads();
+        STAMP(d, 0);
         if (nChunk % g.cpf == g.cpf - 1) {                                  // :171-178
             pitch_chunk_cont(g, c, d, L, nChunk, pS, s);
             __syncthreads();
@@ -807,6 +969,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
         for (int i = tid; i < g.eLen; i += nt) ge[i] = L.eF[i];
         for (int i = tid; i < g.F; i += nt) { go[i] = L.oE[i]; gy[i] = L.yF[i]; }
     }
+    STAMP(d, 11);
 }
 
 // ------------------------------------------------------------------------------------------------

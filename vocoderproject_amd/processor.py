@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvp_amd.so")
+LIB_PATH = os.environ.get("VP_AMD_LIB") or os.path.join(_HERE, "libvp_amd.so")   # VP_AMD_LIB: diagnostic builds only
 
 PARAM_IDS = ("gainPitch", "gainVoice", "gainSynth", "gainVoc", "lpcVoice", "lpcPitch",
              "lpcSynth", "keyPitch", "pitchBool", "vocBool")
@@ -78,6 +78,7 @@ def load_library():
     L.vp_kernel_slot_name.argtypes = [C.c_int]
     L.vp_kernel_slot_name.restype = C.c_char_p
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
+    L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vp_error_string.argtypes = [C.c_int]
     L.vp_error_string.restype = C.c_char_p
     L.vp_last_error.argtypes = [vp]
@@ -204,6 +205,12 @@ class BatchVocoderProcessor:
         c = (C.c_long * 5)()
         self._chk(self.L.vp_read_ub_counters(self.h, c))
         return list(c)
+
+    def debug_stamps(self, reset=True):
+        """Diagnostic build only: per-phase microseconds accumulated by workgroup 0."""
+        v = (C.c_ulonglong * 64)()
+        self._chk(self.L.vp_debug_read_stamps(self.h, v, int(bool(reset))))
+        return [t / 100.0 for t in v]
 
     def profile_enable(self, on=True):
         self._chk(self.L.vp_profile_enable(self.h, int(bool(on))))
