@@ -17,6 +17,11 @@
 
 #define WAVE 64
 
+// explicit LDS address space: keeps the compiler on ds_read/ds_write instead of flat accesses
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) int lds_i32;
+
 // Diagnostic build only (-DVP_STAMPS): workgroup 0 / thread 0 accumulates, per phase id, the
 // 100 MHz wall-clock ticks spent since the previous stamp into d.dbg[id].  No stamp executes in
 // the product build.
@@ -169,7 +174,8 @@ __device__ __forceinline__ double bcast_f64(double v, int src)
 // reference's order (i = 1..p-1, left to right) by broadcasting the per-lane products one after
 // the other, so the result is bit-identical to the serial recursion; the products and the
 // coefficient update run lane-parallel.  All 64 lanes must call it (wave-uniform arguments).
-__device__ void levinson_wave(const double *r, double *a, int order, int aLen, double eps)
+template <class RP, class AP>
+__device__ __forceinline__ void levinson_wave(RP r, AP a, int order, int aLen, double eps)
 {
     const int lane = threadIdx.x & 63;
     if (fabs(r[0]) < eps) {                        // :110-114 (floating abs intended)
@@ -213,7 +219,8 @@ __device__ void levinson_wave(const double *r, double *a, int order, int aLen, d
 // Left-to-right sum of e[i]^2, i = 0..n-1 (VocoderProcess.cpp:250), by one wavefront: lane l holds
 // the squares of i = 64 j + l; they are folded into the running sum in index order by broadcast.
 // All 64 lanes must call it; every lane returns the sum.
-__device__ double energy_wave(const double *e, int n)
+template <class EP>
+__device__ __forceinline__ double energy_wave(EP e, int n)
 {
     const int lane = threadIdx.x & 63;
     double E = 0.0;
@@ -232,47 +239,61 @@ __device__ double energy_wave(const double *e, int n)
 // The chain of (order+1) dependent double operations per sample is irreducible without changing
 // the rounding, so the job here is to make every step cost one VALU issue: coefficients and the
 // last P outputs live in registers (static indices: four samples per trip, history shifted by
-// four), x/y stream through LDS.  hist[j] = y[-1-j] (j < order) or nullptr for a zero state;
-// taps beyond `order` are skipped in groups of four (a[] is zero-padded inside the last group:
-// subtracting 0*h is exact).  n must be a multiple of 4.
-template <int P>
-__device__ void iir_exact_lane(const double *x, double *y, int n, const double *aL, int order, const double *hist, double gmul)
+// four), x/y stream through LDS.  hist[j] = y[-1-j] (j < order) or nullptr for a zero state.
+// Taps order < k <= P run with a[k] = 0: subtracting 0*h leaves the sum unchanged (at most the
+// sign of an exact zero differs).  n must be a multiple of 4.
+// v_mul_f64 / v_add_f64 with a pinned program order (asm volatile statements keep their relative
+// order).  Measured on gfx950 (tools/ubench_chain2.hip): a dependent fp64 op completes in ~8 cycles,
+// a wave can issue one every ~4, so a chain step costs 8 cycles provided the NEXT products are
+// already in flight; hipcc's own schedule put each product right in front of its subtract
+// (16 cycles per tap).  Plain VALU ops on VGPR operands: hardware interlocks cover the dependencies.
+#define VP_MUL64(D, A, B) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(D) : "v"(A), "v"(B))
+#define VP_SUB64(ACC, T) asm volatile("v_add_f64 %0, %0, -%1" : "+v"(ACC) : "v"(T))
+#define VP_COPY64(D, S) asm("v_mul_f64 %0, %1, 1.0" : "=v"(D) : "v"(S))
+
+template <int P, class XP, class YP, class AP, class HP>
+__device__ __forceinline__ void iir_exact_lane(XP x, YP y, int n, AP aL, int order, HP hist, double gmul)
 {
-    static_assert(P % 4 == 0, "P multiple of 4");
+    static_assert(P % 4 == 0 && P >= 4, "P multiple of 4");
     double a[P + 1], h[P + 4];
 #pragma unroll
     for (int k = 1; k <= P; k++) a[k] = (k <= order) ? aL[k] : 0.0;
 #pragma unroll
-    for (int j = 0; j < P; j++) h[j] = (hist != nullptr && j < order) ? hist[j] : 0.0;
-    const int groups = (order + 3) >> 2;
+    for (int j = 0; j < P; j++) h[j] = (hist && j < order) ? hist[j] : 0.0;
     for (int i = 0; i < n; i += 4) {
         double yn[4];
+        const double xin[4] = {x[i], x[i + 1], x[i + 2], x[i + 3]};
 #pragma unroll
         for (int s2 = 0; s2 < 4; s2++) {
-            double acc = gmul * x[i + s2];
+            // tap k multiplies y[i+s2-k]: one of this trip's fresh outputs (k <= s2) or history
+#define VP_HV(K) (((K) <= s2) ? yn[s2 - (K) < 0 ? 0 : s2 - (K)] : h[(K) - 1 - s2])
+            double acc = gmul * xin[s2];
+            double t[3];
+            VP_MUL64(t[2 % 3], VP_HV(2), a[2]);           // independent of the sample just finished
+            VP_MUL64(t[3 % 3], VP_HV(3), a[3]);
+            VP_MUL64(t[1 % 3], VP_HV(1), a[1]);           // needs y[i+s2-1]: the one unavoidable wait
 #pragma unroll
-            for (int gq = 0; gq < P / 4; gq++) {
-                if (gq < groups) {
-#pragma unroll
-                    for (int kk = 1; kk <= 4; kk++) {
-                        const int k = gq * 4 + kk;
-                        const double hv = (k <= s2) ? yn[s2 - k] : h[k - 1 - s2];
-                        acc -= hv * a[k];
-                    }
-                }
+            for (int k = 1; k <= P; k++) {
+                VP_SUB64(acc, t[k % 3]);
+                if (k + 3 <= P) VP_MUL64(t[k % 3], VP_HV(k + 3), a[k + 3]);   // refill the slot just consumed
             }
             yn[s2] = acc;
+#undef VP_HV
         }
+        // history shift.  A plain double copy compiles to v_mov_b64, measured at ~12 ns per wave
+        // instruction on gfx950 (tools/ubench_chain.hip) against 1.9 ns for an fp64 multiply, so
+        // the copies are written as exact multiplications by 1.0.
 #pragma unroll
-        for (int j = P - 1; j >= 4; j--) h[j] = h[j - 4];
-        h[3] = yn[0]; h[2] = yn[1]; h[1] = yn[2]; h[0] = yn[3];
+        for (int j = P - 1; j >= 4; j--) VP_COPY64(h[j], h[j - 4]);
+        VP_COPY64(h[3], yn[0]); VP_COPY64(h[2], yn[1]); VP_COPY64(h[1], yn[2]); VP_COPY64(h[0], yn[3]);
         y[i] = yn[0]; y[i + 1] = yn[1]; y[i + 2] = yn[2]; y[i + 3] = yn[3];
     }
 }
 
 // Generic (any order, any n) form of the same recursion with the history read back from y[]:
 // y must be preceded by its own past (y[-k] valid for k <= min(order, i0 + i)).
-__device__ void iir_exact_generic(const double *x, double *y, int n, const double *aL, int order, int i0, double gmul)
+template <class XP, class YP, class AP>
+__device__ __forceinline__ void iir_exact_generic(XP x, YP y, int n, AP aL, int order, int i0, double gmul)
 {
     for (int i = 0; i < n; i++) {
         double acc = gmul * x[i];
@@ -282,13 +303,19 @@ __device__ void iir_exact_generic(const double *x, double *y, int n, const doubl
     }
 }
 
-// Dispatch on the order (wave-uniform).  hist as in iir_exact_lane; i0 = number of valid past
+// Dispatch on the (wave-uniform) order.  hist as in iir_exact_lane; i0 = number of valid past
 // outputs before y[0] (only used by the generic path).
-__device__ void iir_exact(const double *x, double *y, int n, const double *aL, int order, const double *hist, int i0, double gmul)
+template <class XP, class YP, class AP, class HP>
+__device__ __forceinline__ void iir_exact(XP x, YP y, int n, AP aL, int order_, HP hist, int i0, double gmul)
 {
-    if ((n & 3) == 0 && order <= 16) iir_exact_lane<16>(x, y, n, aL, order, hist, gmul);
-    else if ((n & 3) == 0 && order <= 32) iir_exact_lane<32>(x, y, n, aL, order, hist, gmul);
-    else if ((n & 3) == 0 && order <= 48) iir_exact_lane<48>(x, y, n, aL, order, hist, gmul);
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+    const bool q = (__builtin_amdgcn_readfirstlane(n) & 3) == 0;
+    if (q && order <= 8) iir_exact_lane<8>(x, y, n, aL, order, hist, gmul);
+    else if (q && order <= 16) iir_exact_lane<16>(x, y, n, aL, order, hist, gmul);
+    else if (q && order <= 24) iir_exact_lane<24>(x, y, n, aL, order, hist, gmul);
+    else if (q && order <= 32) iir_exact_lane<32>(x, y, n, aL, order, hist, gmul);
+    else if (q && order <= 40) iir_exact_lane<40>(x, y, n, aL, order, hist, gmul);
+    else if (q && order <= 48) iir_exact_lane<48>(x, y, n, aL, order, hist, gmul);
     else iir_exact_generic(x, y, n, aL, order, i0, gmul);
 }
 
@@ -312,15 +339,16 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
     if (!(d.gate[s * 2 + 0] && d.gate[s * 2 + 1])) return;     // :199-204, whole workgroup
 
     const int W = g.W, oV = c.orderVoice, oS = c.orderSynth;
-    double *win = smem;                       // [W] shared by all waves
-    double *hist = win + W;                   // [2][10] EeVoiceArr, EeSynthArr
-    double *roundE = hist + 20;               // [2][8]
-    double *gArr = roundE + 16;               // [8]
-    double *wbase = gArr + 8 + (size_t)wave * voc_wave_doubles(W);
-    double *A = wbase, *B = A + W, *Cc = B + W, *D = Cc + W;
-    float *xv = (float *)A, *xsy = xv + W;
-    double *rV = D + W, *aV = rV + (VP_ORDER_MAX + 1), *aPV = aV + (VP_ORDER_MAX + 1);
-    double *rS = aPV + (VP_ORDER_MAX + 1), *aS = rS + (VP_ORDER_MAX_SYNTH + 1), *aPS = aS + (VP_ORDER_MAX_SYNTH + 1);
+    lds_f64 *sm = (lds_f64 *)smem;
+    lds_f64 *win = sm;                        // [W] shared by all waves
+    lds_f64 *hist = win + W;                  // [2][10] EeVoiceArr, EeSynthArr
+    lds_f64 *roundE = hist + 20;              // [2][8]
+    lds_f64 *gArr = roundE + 16;              // [8]
+    lds_f64 *wbase = gArr + 8 + (size_t)wave * voc_wave_doubles(W);
+    lds_f64 *A = wbase, *B = A + W, *Cc = B + W, *D = Cc + W;
+    lds_f32 *xv = (lds_f32 *)A, *xsy = xv + W;
+    lds_f64 *rV = D + W, *aV = rV + (VP_ORDER_MAX + 1), *aPV = aV + (VP_ORDER_MAX + 1);
+    lds_f64 *rS = aPV + (VP_ORDER_MAX + 1), *aS = rS + (VP_ORDER_MAX_SYNTH + 1);
 
     for (int i = tid; i < W; i += blockDim.x) win[i] = d.vocWin[i];
     if (tid < 20) hist[tid] = d.EeArr[(size_t)s * 20 + tid];
@@ -355,8 +383,8 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
             for (int q = lane; q < nLags; q += WAVE) {
                 const bool isV = q <= oV;
                 const int m = isV ? q : q - (oV + 1);
-                const double *xw = isV ? B : Cc;
-                const float *x = isV ? xv : xsy;
+                const lds_f64 *xw = isV ? B : Cc;
+                const lds_f32 *x = isV ? xv : xsy;
                 double sum = 0.0;
                 for (int n = 0; n < W - m; n++) sum += xw[n] * (double)x[n + m] * win[n + m];
                 sum /= (double)W;
@@ -400,7 +428,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
         STAMP(d, 20);
 
         // filterIIR part 1 (VocoderProcess.cpp:264-275): 10-deep energy histories, window by window.
-        if (tid == 0) {
+        if (wave == 0) {                                 // all lanes redundantly (full EXEC)
             for (int j = 0; j < nAct; j++) {
                 for (int i = 9; i > 0; i--) { hist[i] = hist[i - 1]; hist[10 + i] = hist[10 + i - 1]; }
                 hist[0] = roundE[j];
@@ -419,7 +447,18 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
         STAMP(d, 21);
 
         // filterIIR part 2 (:277-286): all-pole recursion, serial in i; one lane per window.
-        if (active && lane == 0) iir_exact(A, B, W, aV, oV, nullptr, 0, gArr[wave]);
+        // One lane per window, all windows of the round in ONE wavefront: chains running in
+        // different waves of a workgroup slow each other down almost linearly (measured,
+        // tools/ubench_iir.hip), chains in different lanes of one wave cost nothing extra.
+        // The chain code must run with EVERY lane of the wave active: executed under a one-lane
+        // EXEC mask it is slower and, worse, chains in different waves then serialise (measured,
+        // tools/ubench_iir.hip modes 1 vs 3).  Spare lanes redo the last window (identical stores).
+        if (wave == 0) {
+            const int wj = min(lane, nAct - 1);
+            lds_f64 *wb = gArr + 8 + (size_t)wj * voc_wave_doubles(W);        // window `wj` of this round
+            const lds_f64 *Aj = wb, *aVj = wb + 4 * (size_t)W + (VP_ORDER_MAX + 1);
+            iir_exact(Aj, wb + W, W, aVj, oV, (const lds_f64 *)nullptr, 0, gArr[wj]);
+        }
         __syncthreads();
         STAMP(d, 22);
         if (active)                                      // gainVoc * out[i] * stWindow[i] (:291-295)
@@ -438,7 +477,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
                 for (int j = jlo; j <= jhi; j++) {
                     int i = t - j * g.h;
                     if (i >= 0 && i < W) {
-                        const double *Bj = gArr + 8 + (size_t)j * voc_wave_doubles(W) + W;
+                        const lds_f64 *Bj = gArr + 8 + (size_t)j * voc_wave_doubles(W) + W;
                         v += Bj[i];
                     }
                 }
@@ -461,15 +500,17 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
 //      yF   [F]         yFrame
 //      dY   [tauMax+1]  yinTemp (+ guard slot), cum [tauMax]
 //      r, aPrev [101]
+typedef __attribute__((address_space(3))) VpPitchState lds_state;
+typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
-    double *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev;
-    VpPitchState *st;
-    MinIdx *part;      // [8]
-    int *ishare;       // [4]
+    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev;
+    lds_state *st;
+    lds_minidx *part;  // [8]
+    int *ishare;       // [4] (generic pointer: used with atomicMin)
 };
 
 // argExt over frame positions [lo, hi) (PitchProcess.cpp:752-776), whole workgroup cooperates.
-__device__ int block_arg_min(const PitchLds &L, int toKeep, int lo, int hi)
+__device__ __forceinline__ int block_arg_min(const PitchLds &L, int toKeep, int lo, int hi)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     MinIdx m; m.v = L.xs[toKeep + lo]; m.i = lo;          // ext = sample at idxStart, always read
@@ -478,15 +519,15 @@ __device__ int block_arg_min(const PitchLds &L, int toKeep, int lo, int hi)
         m = min_first(m, o);
     }
     m = wave_min_first(m);
-    if ((tid & 63) == 0) L.part[tid >> 6] = m;
+    if ((tid & 63) == 0) { L.part[tid >> 6].v = m.v; L.part[tid >> 6].i = m.i; }
     __syncthreads();
-    MinIdx b = L.part[0];
-    for (int w = 1; w < (nt >> 6); w++) b = min_first(b, L.part[w]);
+    MinIdx b; b.v = L.part[0].v; b.i = L.part[0].i;
+    for (int w = 1; w < (nt >> 6); w++) { MinIdx o; o.v = L.part[w].v; o.i = L.part[w].i; b = min_first(b, o); }
     __syncthreads();
     return b.i;
 }
 
-__device__ __forceinline__ int marks_back(const int *v, int n, unsigned long long *ub)
+__device__ __forceinline__ int marks_back(const lds_i32 *v, int n, unsigned long long *ub)
 {
     // std::vector::back(); empty -> the reference reads the word before the heap block (0 on glibc)
     if (n > 0) return v[n - 1];
@@ -496,9 +537,9 @@ __device__ __forceinline__ int marks_back(const int *v, int n, unsigned long lon
 
 // PitchProcess::pitchMarks (PitchProcess.cpp:455-567).  All threads walk the control flow (it is
 // uniform); thread 0 owns the writes to the mark arrays; arg-min searches use the whole group.
-__device__ void pitch_marks(const VpGeom &g, const PitchLds &L, unsigned long long *ub)
+__device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, unsigned long long *ub)
 {
-    VpPitchState *st = L.st;
+    lds_state *st = L.st;
     const int tid = threadIdx.x;
     if (tid == 0) {
         for (int i = 0; i < st->nAn; i++) st->prevAnMarks[i] = st->anMarks[i] - g.H;   // prevAnMarks = anMarks; -= hop
@@ -513,7 +554,7 @@ __device__ void pitch_marks(const VpGeom &g, const PitchLds &L, unsigned long lo
     const double pitch = st->pitch, prevPitch = st->prevPitch;
     const int period = st->period, prevPeriod = st->prevPeriod, pvp = st->prevVoicedPeriod;
     int n = 0, front = 0, back = 0;                  // uniform mirrors of anMarks.size()/front()/back()
-    int *an = st->anMarks;
+    lds_i32 *an = st->anMarks;
     __syncthreads();
 
 #define PUSH_BACK(val) do { int _v = (val); if (tid == 0) { if (n < VP_MARKS) an[n] = _v; if (n + 1 > 20) atomicAdd(&ub[4], 1ULL); } \
@@ -584,7 +625,7 @@ __device__ void pitch_marks(const VpGeom &g, const PitchLds &L, unsigned long lo
 }
 
 // Notes::getClosestFreq (Notes.cpp:79-110) on the precomputed table of `key`.
-__device__ double notes_closest(const double *freq, int size, double pitch)
+__device__ __forceinline__ double notes_closest(const double *freq, int size, double pitch)
 {
     int lo = 0, hi = size;
     while (lo < hi) {
@@ -600,7 +641,7 @@ __device__ double notes_closest(const double *freq, int size, double pitch)
 }
 
 // PitchProcess::placeStMarks (PitchProcess.cpp:573-658), one lane.
-__device__ void place_st_marks(const VpGeom &g, const VpCall &c, const VpDev &d, VpPitchState *st)
+__device__ __forceinline__ void place_st_marks(const VpGeom &g, const VpCall &c, const VpDev &d, lds_state *st)
 {
     unsigned long long *ub = d.ub;
     for (int i = 0; i < st->nSt; i++) st->prevStMarks[i] = st->stMarks[i] - g.H;
@@ -650,17 +691,17 @@ __device__ void place_st_marks(const VpGeom &g, const VpCall &c, const VpDev &d,
     while (st->stMarks[n - 1] + periodNew < g.F) {
         int v = st->stMarks[n - 1] + periodNew;
         if (n < VP_MARKS) st->stMarks[n] = v;
-        if (n + 1 > 20) atomicAdd(&ub[4], 1ULL);
+        if (n + 1 > 20 && threadIdx.x == 0) atomicAdd(&ub[4], 1ULL);
         if (n < VP_MARKS) n++; else break;
     }
     st->nSt = n;
 }
 
 // PitchProcess::getClosestAnMarkIdx (PitchProcess.cpp:788-831); uniform, read-only.
-__device__ int closest_an_mark_idx(const VpGeom &g, const VpPitchState *st, int stMark, int T, int nChunk,
-                                   int pS, unsigned long long *ub)
+__device__ __forceinline__ int closest_an_mark_idx(const VpGeom &g, const lds_state *st, int stMark, int T, int nChunk,
+                                                   int pS, unsigned long long *ub)
 {
-    const int *an = st->anMarks;
+    const lds_i32 *an = st->anMarks;
     const int nAn = st->nAn;
     int lo = 0, hi = nAn;
     while (lo < hi) {
@@ -686,9 +727,9 @@ __device__ int closest_an_mark_idx(const VpGeom &g, const VpPitchState *st, int 
 
 // PitchProcess::psola (PitchProcess.cpp:665-741) + interp (:842-870): grains in order, the output
 // samples of one grain in parallel.
-__device__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS)
+__device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS)
 {
-    VpPitchState *st = L.st;
+    lds_state *st = L.st;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
     const int nG = 2 * T + 1;
@@ -750,23 +791,24 @@ __device__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nC
     STAMP(d, 7);
 }
 
-__device__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk)
+__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk)
 {
-    // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion, one lane
-    if (threadIdx.x == 0) {
+    // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  All 64 lanes of wave 0
+    // run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
+    if (threadIdx.x < WAVE) {
         const int shift = nChunk * g.C, order = g.orderPitch;
         // history y[shift-1-j]; the frame starts from a zero state (yFrame is zero-filled at the
         // frame start, so reading it as history for shift > 0 is the same thing)
-        double *hist = L.cum;                           // yinTemp scratch is free here
+        lds_f64 *hist = L.cum;                          // yinTemp scratch is free here
         const int nh = min(order, shift);
         for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
-        iir_exact(L.oE + shift, L.yF + shift, g.C, L.st->a, order, hist, shift, 1.0);
+        iir_exact(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
     __syncthreads();
     STAMP(d, 8);
 }
 
-__device__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+__device__ __forceinline__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
                                   int nChunk, int pS, int s)
 {
     // PitchProcess::fillOutputBuffer (PitchProcess.cpp:328-342)
@@ -779,13 +821,15 @@ __device__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev 
     STAMP(d, 9);
 }
 
-__device__ void pitch_chunk_cont(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
-                                 int nChunk, int pS, int s)
+// First half of PitchProcess::processChunkCont (PitchProcess.cpp:253-259): residual of the new samples.
+// Returns true when the chunk has work (analysis marks exist); the caller then runs the shared
+// tail psola -> filterIIR -> fillOutputBuffer (:262-268).
+__device__ __forceinline__ bool pitch_chunk_cont_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+                                                     int nChunk, int pS, int s)
 {
-    // PitchProcess::processChunkCont (PitchProcess.cpp:253-271)
-    if (L.st->nAn == 0) return;
+    if (L.st->nAn == 0) return false;
     const int order = g.orderPitch;
-    const double *a = L.st->a;
+    const lds_f64 *a = L.st->a;
     for (int i = threadIdx.x; i < g.C; i += blockDim.x) {                   // filterFIR(F-C, C, toKeep+F+(n-1)C)
         int xi = g.toKeep + g.F - g.C + i;
         double e = a[0] * L.xs[xi];
@@ -794,22 +838,21 @@ __device__ void pitch_chunk_cont(const VpGeom &g, const VpCall &c, const VpDev &
     }
     __syncthreads();
     STAMP(d, 10);
-    psola(g, d, L, nChunk, pS);
-    pitch_iir(g, d, L, nChunk);
-    pitch_fill_output(g, c, d, L, nChunk, pS, s);
+    return true;
 }
 
-__device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
-                                  int pS, int s)
+// PitchProcess::processChunkStart (PitchProcess.cpp:203-236) up to the residual; returns
+// 0: gate closed (no output at all), 1: output only (no analysis marks: yFrame is zero), 2: full tail.
+__device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+                                                     int pS, int s)
 {
-    // PitchProcess::processChunkStart (PitchProcess.cpp:203-247)
-    VpPitchState *st = L.st;
+    lds_state *st = L.st;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
         __syncthreads();
         if (tid == 0) { st->nAn = 0; st->prevPitch = 0; st->gateOpen = 0; }
         __syncthreads();
-        return;
+        return 0;
     }
     for (int i = tid; i < g.eLen; i += nt) L.eF[i] = 0.0;                  // :216-218
     for (int i = tid; i < g.F; i += nt) { L.oE[i] = 0.0; L.yF[i] = 0.0; }
@@ -826,7 +869,7 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
         const int base = g.toKeep - g.tauMax;
         for (int k = tid; k < g.tauMax; k += nt) {
             double accv = 0.0;
-            const double *xa = L.xs + base, *xb = L.xs + base + k;
+            const lds_f64 *xa = L.xs + base, *xb = L.xs + base + k;
 #pragma unroll 4
             for (int i = 0; i < g.F; i++) {
                 double df = xa[i] - xb[i];
@@ -840,7 +883,7 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
     // Its result is only used when analysis marks exist (:230-233).
     {
         const int order = g.orderPitch;
-        const double *x = L.xs + g.toKeep;
+        const lds_f64 *x = L.xs + g.toKeep;
         for (int m = nt - 1 - tid; m <= order && m >= 0; m += nt) {       // highest threads: they have no YIN lag
             double sum = 0.0;
             for (int n = 0; n < g.F - m; n++) sum += x[n] * x[n + m];
@@ -849,7 +892,7 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
     }
     __syncthreads();
     STAMP(d, 1);
-    if (tid == 0) {                                                          // :395-402 running sum, in order
+    if (tid < WAVE) {                                                        // :395-402 running sum, in order (all lanes redundantly)
         L.dY[0] = 1.0;
         double tmp = 0;
         for (int k = 1; k < g.tauMax; k++) { tmp += L.dY[k]; L.cum[k] = tmp; }
@@ -877,15 +920,15 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
     STAMP(d, 2);
     pitch_marks(g, L, d.ub);
     STAMP(d, 3);
-    if (tid == 0) place_st_marks(g, c, d, st);
+    if (tid < WAVE) place_st_marks(g, c, d, st);                            // all lanes redundantly (full EXEC)
     __syncthreads();
     STAMP(d, 4);
     if (st->nAn != 0) {
-        if (tid < WAVE) levinson_wave(L.r, st->a, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        if (tid < WAVE) levinson_wave(L.r, (lds_f64 *)st->a, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
         __syncthreads();
         STAMP(d, 5);
         const int order = g.orderPitch;
-        const double *a = st->a;
+        const lds_f64 *a = st->a;
         for (int j = tid; j < g.toKeep + g.F; j += nt) {                    // filterFIR(-toKeep, toKeep+F, 0) :280-302
             double e = a[0] * L.xs[j];
             int kmax = min(order, j);
@@ -895,10 +938,9 @@ __device__ void pitch_chunk_start(const VpGeom &g, const VpCall &c, const VpDev 
         if (tid == 0) st->stMarkIdx = 0;
         __syncthreads();
         STAMP(d, 6);
-        psola(g, d, L, 0, pS);
-        pitch_iir(g, d, L, 0);
+        return 2;
     }
-    pitch_fill_output(g, c, d, L, 0, pS, s);
+    return 1;
 }
 
 __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
@@ -906,7 +948,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
     extern __shared__ double smem[];
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     PitchLds L;
-    L.xs = smem;
+    L.xs = (lds_f64 *)smem;
     L.eF = L.xs + (g.toKeep + g.F);
     L.oE = L.eF + g.eLen;
     L.yF = L.oE + g.F;
@@ -914,13 +956,13 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
     L.cum = L.dY + (g.tauMax + 1);
     L.r = L.cum + (g.tauMax + 1);
     L.aPrev = L.r + (VP_ORDER_MAX + 1);
-    L.part = (MinIdx *)(L.aPrev + (VP_ORDER_MAX + 1));
-    L.st = (VpPitchState *)(L.part + 8);
-    L.ishare = (int *)(L.st + 1);
+    L.part = (lds_minidx *)(L.aPrev + (VP_ORDER_MAX + 1));
+    L.st = (lds_state *)(L.part + 8);
+    L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)L.xs)) * sizeof(int));
 
     {   // state in
         const int *src = (const int *)(d.pitch + s);
-        int *dst = (int *)L.st;
+        lds_i32 *dst = (lds_i32 *)L.st;
         for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
     }
     STAMP0(d);
@@ -941,27 +983,36 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
             L.xs[j] = (double)vr[ring_pos(c.currCounter, pS - g.toKeep + j, g.inSize)];
         __syncthreads();
         STAMP(d, 0);
-        if (nChunk % g.cpf == g.cpf - 1) {                                  // :171-178
-            pitch_chunk_cont(g, c, d, L, nChunk, pS, s);
+        // PitchProcess::process (:171-189): a step is [Cont of the running frame] then, when a new
+        // frame starts here, [Start]; both feed the same tail psola -> filterIIR -> fillOutputBuffer.
+        for (int sub = 0; sub < 2; sub++) {
+            int mode;                       // 0 nothing, 1 output only, 2 psola + IIR + output
+            int nC;
+            if (sub == 0) {
+                if (nChunk == 0) continue;
+                nC = nChunk;
+                mode = pitch_chunk_cont_pre(g, c, d, L, nChunk, pS, s) ? 2 : 0;
+            } else {
+                if (nChunk == g.cpf - 1) nChunk = 0;
+                if (nChunk != 0) break;
+                nC = 0;
+                mode = pitch_chunk_start_pre(g, c, d, L, pS, s);
+            }
+            if (mode == 2) {
+                psola(g, d, L, nC, pS);
+                pitch_iir(g, d, L, nC);
+            }
+            if (mode >= 1) pitch_fill_output(g, c, d, L, nC, pS, s);
             __syncthreads();
-            nChunk = 0;
-            pitch_chunk_start(g, c, d, L, pS, s);
-            nChunk += 1;
-            nChunk %= g.cpf;
-        } else if (nChunk == 0) {
-            pitch_chunk_start(g, c, d, L, pS, s);
-            nChunk += 1;
-        } else {
-            pitch_chunk_cont(g, c, d, L, nChunk, pS, s);
-            nChunk += 1;
         }
+        nChunk += 1;
         __syncthreads();
         pS += g.C;
     }
 
     {   // state out
         int *dst = (int *)(d.pitch + s);
-        const int *src = (const int *)L.st;
+        const lds_i32 *src = (const lds_i32 *)L.st;
         for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
     }
     if (nChunk != 0 && L.st->nAn != 0) {
