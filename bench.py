@@ -36,13 +36,26 @@ HBM_PEAK_GBS = 8000.0                                                  # MI355X_
 UNIQUE_BLOCKS = 16                                                      # synthetic input ring, cycled
 
 
+def usable_cores():
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(mode, N, seconds_target=12.0):
     """Time the CPU oracle on all host cores: one stream per task (ctypes releases the GIL)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py as O
     from vocoderproject_amd.synth import make_streams
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     params = dict(pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"))
     # calibrate on one stream
     x1 = np.ascontiguousarray(make_streams(1, N * 8).numpy())[0]
@@ -51,19 +64,22 @@ def cpu_baseline(mode, N, seconds_target=12.0):
     t = time.perf_counter()
     o.run(x1)
     per_block = (time.perf_counter() - t) / 8
-    blocks = int(max(16, min(512, seconds_target / max(per_block, 1e-6))))
+    blocks = 128
+    reps = int(max(1, min(64, round(seconds_target / max(per_block * blocks, 1e-6)))))
     n_streams = cores
     x = np.ascontiguousarray(make_streams(n_streams, N * blocks).numpy())
 
     def work(s):
         oo = O.OracleStream(**params)
         oo.prepare_to_play(FS, N)
-        oo.run(x[s])
+        for _ in range(reps):            # the stream simply continues: state carries over
+            oo.run(x[s])
 
     t = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(work, range(n_streams)))
     dt = time.perf_counter() - t
+    blocks *= reps
     frames = n_streams * blocks * N / HOP
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_streams} streams x {blocks} blocks of {N} samples, mode={mode}, one oracle stream per thread, "
