@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/vp_amd.h declares,
+and FAILS LOUDLY without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vocoderproject_amd import build
+    return C.CDLL(build.build())
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "vp_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vp_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    syms = _declared_symbols()
+    assert len(syms) >= 20 and "vp_process_block" in syms and "vp_prepare_to_play" in syms
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/vp_amd.h but not exported"
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.vp_abi_version() == 1
+    lib.vp_error_string.restype = C.c_char_p
+    assert lib.vp_error_string(0) == b"ok"
+    assert lib.vp_error_string(-3) == b"Invalid overlap"          # VocoderProcess.cpp:112
+    assert b"no CPU fallback" in lib.vp_error_string(-6)
+
+
+def test_default_params_match_reference_layout(lib):
+    from vocoderproject_amd.processor import VpParams
+    p = VpParams()
+    lib.vp_default_params(C.byref(p))
+    # PluginProcessor.cpp:41-69
+    assert (p.gainPitch, p.gainVoice, p.gainSynth, p.gainVoc) == (0.0, -60.0, -60.0, 0.0)
+    assert (p.lpcVoice, p.lpcPitch, p.lpcSynth, p.keyPitch, p.pitchBool, p.vocBool) == (40, 15, 5, 12, 1, 1)
+
+
+def test_create_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.vp_create(0, C.byref(h))
+    assert rc == -6 and not h.value                                 # VP_ERR_NO_DEVICE
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    with pytest.raises(VpError):
+        BatchVocoderProcessor()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vocoderproject_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                assert "import oracle" not in t and "from oracle" not in t and "vp_oracle" not in t, f

@@ -1,0 +1,68 @@
+"""Sharding of the stream batch across ranks (one process per GPU).
+
+Streams are independent plugin instances (PluginProcessor.h:69-73: each instance owns its MyBuffer and
+processes), so the batch shards embarrassingly: rank r owns the contiguous block
+[shard_range(S, r, W)) for the whole run and keeps its per-stream state resident on its GPU.
+No collective is needed on the data path.  When the caller holds the whole batch on one rank,
+`scatter_streams` / `gather_streams` move it with torch.distributed point-to-point traffic
+(backend "nccl" = RCCL over xGMI on a GPU node, "gloo" in the CPU tests): a root fan-out uses each
+peer's direct link once, there is no reduction anywhere.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_streams, rank, world):
+    """Contiguous [lo, hi) of streams owned by `rank`; sizes differ by at most one (ragged batches)."""
+    base, rem = divmod(int(n_streams), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def shard_sizes(n_streams, world):
+    return [shard_range(n_streams, r, world)[1] - shard_range(n_streams, r, world)[0] for r in range(world)]
+
+
+def scatter_streams(x_root, n_streams, tail_shape, dtype, device, src=0, group=None):
+    """Rank `src` holds x_root [n_streams, *tail_shape]; every rank returns its own shard.
+
+    Point-to-point isend/irecv (no padding needed for ragged shards)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_streams, rank, world)
+    mine = torch.empty((hi - lo, *tail_shape), dtype=dtype, device=device)
+    if rank == src:
+        reqs = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_streams, r, world)
+            if r == src:
+                mine.copy_(x_root[rlo:rhi])
+            elif rhi > rlo:
+                reqs.append(dist.isend(x_root[rlo:rhi].contiguous(), dst=r, group=group))
+        for q in reqs:
+            q.wait()
+    elif hi > lo:
+        dist.recv(mine, src=src, group=group)
+    return mine
+
+
+def gather_streams(y_local, n_streams, dst=0, group=None):
+    """Inverse of scatter_streams: rank `dst` returns [n_streams, *tail], the others None."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    tail = tuple(y_local.shape[1:])
+    if rank == dst:
+        out = torch.empty((n_streams, *tail), dtype=y_local.dtype, device=y_local.device)
+        reqs = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_streams, r, world)
+            if r == dst:
+                out[rlo:rhi].copy_(y_local)
+            elif rhi > rlo:
+                reqs.append((dist.irecv(out[rlo:rhi], src=r, group=group)))
+        for q in reqs:
+            q.wait()
+        return out
+    lo, hi = shard_range(n_streams, rank, world)
+    if hi > lo:
+        dist.send(y_local.contiguous(), dst=dst, group=group)
+    return None
