@@ -1,0 +1,108 @@
+// vp_amd.hpp -- header-only C++ adapter over the C ABI (vp_amd.h).
+//
+// `vp::BatchVocoderProcessor` mirrors the call surface of the reference's
+// VocoderAudioProcessor (PluginProcessor.h:24-80) for a batch of streams, so host code written
+// against the plugin reads the same:
+//
+//     vp::BatchVocoderProcessor proc(/*device*/ 0);
+//     proc.setParameter("lpcVoice", 24);              // treeState.getRawParameterValue(id)->store(v)
+//     proc.prepareToPlay(44100.0, 1024, /*streams*/ 256);
+//     proc.processBlock(io);                           // float io[streams][3][N], in place
+//
+// and a `vp::BufferView` with the MyBuffer getters (MyBuffer.h:37-43) for code that sized its own
+// buffers from them.  Errors become exceptions carrying the C status code.
+#pragma once
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "vp_amd.h"
+
+namespace vp {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+// MyBuffer.h:37-43
+struct BufferView {
+    int geom[12];
+    int getSamplesPerBlock() const { return geom[0]; }
+    int getLatency() const { return geom[7]; }
+    int getIdxMax() const { return geom[7] + geom[0]; }
+    int getSamplesToKeep() const { return geom[6]; }
+    int getInSize() const { return geom[8]; }
+    int getNumOutChannels() const { return 2; }
+};
+
+class BatchVocoderProcessor {
+public:
+    explicit BatchVocoderProcessor(int device = 0)
+    {
+        check(vp_create(device, &h_), "vp_create");                 // createPluginFilter()
+        vp_default_params(&p_);
+    }
+    ~BatchVocoderProcessor() { if (h_) vp_destroy(h_); }
+    BatchVocoderProcessor(const BatchVocoderProcessor &) = delete;
+    BatchVocoderProcessor &operator=(const BatchVocoderProcessor &) = delete;
+
+    // ids and ranges of createParameterLayout() (PluginProcessor.cpp:37-73)
+    void setParameter(const char *id, float v)
+    {
+        vp_params q = p_;
+        if (!std::strcmp(id, "gainPitch")) q.gainPitch = v;
+        else if (!std::strcmp(id, "gainVoice")) q.gainVoice = v;
+        else if (!std::strcmp(id, "gainSynth")) q.gainSynth = v;
+        else if (!std::strcmp(id, "gainVoc")) q.gainVoc = v;
+        else if (!std::strcmp(id, "lpcVoice")) q.lpcVoice = (int)v;
+        else if (!std::strcmp(id, "lpcPitch")) q.lpcPitch = (int)v;
+        else if (!std::strcmp(id, "lpcSynth")) q.lpcSynth = (int)v;
+        else if (!std::strcmp(id, "keyPitch")) q.keyPitch = (int)v;
+        else if (!std::strcmp(id, "pitchBool")) q.pitchBool = (int)v;
+        else if (!std::strcmp(id, "vocBool")) q.vocBool = (int)v;
+        else throw Error(VP_ERR_INVALID_ARG, std::string("unknown parameter ") + id);
+        check(vp_set_params(h_, &q), id);
+        p_ = q;
+    }
+    const vp_params &parameters() const { return p_; }
+
+    void prepareToPlay(double sampleRate, int samplesPerBlock, int nStreams)      // PluginProcessor.cpp:144
+    {
+        check(vp_prepare_to_play(h_, sampleRate, samplesPerBlock, nStreams), "prepareToPlay");
+    }
+    void prepareExplicit(double sampleRate, int samplesPerBlock, int nStreams, int frameLenPitch, int hopPitch,
+                         int wlenVoc, int hopVoc)                                   // :172-181 with explicit sizes
+    {
+        check(vp_prepare_explicit(h_, sampleRate, samplesPerBlock, nStreams, frameLenPitch, hopPitch, wlenVoc, hopVoc),
+              "prepareExplicit");
+    }
+    // processBlock(AudioBuffer<float>&, MidiBuffer&) (:203): io [streams][3][N] in place, host memory
+    void processBlock(float *io) { check(vp_process_block_inplace(h_, io), "processBlock"); }
+    void processBlock(const float *in, float *out) { check(vp_process_block(h_, in, out), "processBlock"); }
+    // device-resident, asynchronous on `hipStream`
+    void processBlockDevice(const float *dIn, float *dOut, void *hipStream = nullptr)
+    {
+        check(vp_process_block_device(h_, dIn, dOut, hipStream), "processBlockDevice");
+    }
+    int getLatencySamples() const { return vp_get_latency(h_); }                   // :183
+    BufferView bufferView() const
+    {
+        BufferView v;
+        check(vp_get_geometry(h_, v.geom), "geometry");
+        return v;
+    }
+    vp_handle *handle() { return h_; }
+
+private:
+    void check(int rc, const std::string &what) const
+    {
+        if (rc != VP_OK)
+            throw Error(rc, what + ": " + vp_error_string(rc) + (h_ ? std::string(" (") + vp_last_error(h_) + ")" : ""));
+    }
+    vp_handle *h_ = nullptr;
+    vp_params p_;
+};
+
+}  // namespace vp
