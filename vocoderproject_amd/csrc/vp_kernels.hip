@@ -870,8 +870,25 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         for (int k = tid; k < g.tauMax; k += nt) {
             double accv = 0.0;
             const lds_f64 *xa = L.xs + base, *xb = L.xs + base + k;
-#pragma unroll 4
-            for (int i = 0; i < g.F; i++) {
+            // eight elements per trip, the next trip's LDS reads issued before this trip's arithmetic
+            // (the sum itself stays strictly left to right)
+            const int F8 = g.F & ~7;
+            double a0[8], b0[8], a1[8], b1[8];
+#define VP_YLOAD(A, B, I) _Pragma("unroll") for (int u = 0; u < 8; u++) { A[u] = xa[(I) + u]; B[u] = xb[(I) + u]; }
+#define VP_YCOMP(A, B) _Pragma("unroll") for (int u = 0; u < 8; u++) { double df = A[u] - B[u]; accv += df * df; }
+            if (F8 > 0) { VP_YLOAD(a0, b0, 0) }
+            for (int i = 0; i < F8; i += 16) {
+                const bool more1 = i + 8 < F8;
+                if (more1) { VP_YLOAD(a1, b1, i + 8) }
+                VP_YCOMP(a0, b0)
+                if (more1) {
+                    if (i + 16 < F8) { VP_YLOAD(a0, b0, i + 16) }
+                    VP_YCOMP(a1, b1)
+                }
+            }
+#undef VP_YLOAD
+#undef VP_YCOMP
+            for (int i = F8; i < g.F; i++) {
                 double df = xa[i] - xb[i];
                 accv += df * df;
             }
@@ -886,21 +903,52 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         const lds_f64 *x = L.xs + g.toKeep;
         for (int m = nt - 1 - tid; m <= order && m >= 0; m += nt) {       // highest threads: they have no YIN lag
             double sum = 0.0;
-            for (int n = 0; n < g.F - m; n++) sum += x[n] * x[n + m];
+            const int cnt = g.F - m, c8 = cnt & ~7;
+            const lds_f64 *xm = x + m;
+            double a0[8], b0[8], a1[8], b1[8];              // same software pipeline as the YIN loop
+#define VP_ALOAD(A, B, I) _Pragma("unroll") for (int u = 0; u < 8; u++) { A[u] = x[(I) + u]; B[u] = xm[(I) + u]; }
+#define VP_ACOMP(A, B) _Pragma("unroll") for (int u = 0; u < 8; u++) { sum += A[u] * B[u]; }
+            if (c8 > 0) { VP_ALOAD(a0, b0, 0) }
+            for (int n = 0; n < c8; n += 16) {
+                const bool more1 = n + 8 < c8;
+                if (more1) { VP_ALOAD(a1, b1, n + 8) }
+                VP_ACOMP(a0, b0)
+                if (more1) {
+                    if (n + 16 < c8) { VP_ALOAD(a0, b0, n + 16) }
+                    VP_ACOMP(a1, b1)
+                }
+            }
+#undef VP_ALOAD
+#undef VP_ACOMP
+            for (int n = c8; n < cnt; n++) sum += x[n] * xm[n];
             L.r[m] = sum / (double)g.F;
         }
     }
     __syncthreads();
     STAMP(d, 1);
-    if (tid < WAVE) {                                                        // :395-402 running sum, in order (all lanes redundantly)
-        L.dY[0] = 1.0;
-        double tmp = 0;
-        for (int k = 1; k < g.tauMax; k++) { tmp += L.dY[k]; L.cum[k] = tmp; }
-        L.dY[g.tauMax] = 0.0;                                                // guard slot (see oracle)
+    if (tid < WAVE) {                                                        // :395-402 running sum tmp += yinTemp[k], in order
+        // every lane of wave 0 runs the same chain (full EXEC); eight entries per trip are read
+        // ahead so that only the dependent adds remain on the critical path
+        const int lane = tid;
+        double run = 0.0;
+        const int n8 = (g.tauMax - 1) & ~7;
+        for (int k0 = 1; k0 < 1 + n8; k0 += 8) {
+            double v[8], cs[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = L.dY[k0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { run += v[u]; cs[u] = run; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) L.cum[k0 + u] = cs[u];
+        }
+        for (int k = 1 + n8; k < g.tauMax; k++) { run += L.dY[k]; L.cum[k] = run; }
+        if (lane == 0) { L.dY[0] = 1.0; L.dY[g.tauMax] = 0.0; }               // :395, guard slot (see oracle)
     }
     __syncthreads();
+    STAMP(d, 12);
     for (int k = 1 + tid; k < g.tauMax; k += nt) L.dY[k] *= (double)k / L.cum[k];
     __syncthreads();
+    STAMP(d, 13);
     for (int k = g.tau0 + tid; k < g.tauMax; k += nt)                      // first tau with d < tol (:431-433)
         if (L.dY[k] < g.yinTol) atomicMin(&L.ishare[0], k);
     __syncthreads();
