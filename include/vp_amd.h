@@ -105,6 +105,16 @@ int vp_process_block_inplace(vp_handle *h, float *io);
  * stream) and the call returns without synchronising. */
 int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void *hip_stream);
 
+/* Arithmetic of the two all-pole synthesis filters (VocoderProcess.cpp:277-286, PitchProcess.cpp:307-322).
+ * VP_IIR_EXACT (default): the reference's summation order, output bit-identical to the CPU restatement.
+ * VP_IIR_FAST: transposed-form recursion with the taps spread over the lanes; differs from EXACT by
+ * rounding only (measured max |diff| ~1e-12 of full scale before the float32 cast); every decision of
+ * the algorithm (pitch, marks, gate) is still bit-identical because none depends on a filter output. */
+#define VP_IIR_EXACT 0
+#define VP_IIR_FAST 1
+int vp_set_iir_mode(vp_handle *h, int mode);
+int vp_get_iir_mode(const vp_handle *h);
+
 /* AudioProcessor::getLatencySamples() after setLatencySamples(max(F, W)) (PluginProcessor.cpp:175,183). */
 int vp_get_latency(const vp_handle *h);
 /* N, F, H, C, W, h, samplesToKeep, latency, inSize, outSize, tauMax, chunksPerFrame

@@ -301,3 +301,53 @@ def test_full_batch_matches_oracle_on_sampled_streams_and_is_batch_invariant():
     dry, p = _gpu_run(x, N, dict(pitchBool=0, vocBool=0, gainVoice=0.0))
     lat = p.getLatencySamples()
     np.testing.assert_array_equal(dry[:, 0, lat:], x[:, 0, :-lat])
+
+
+# ---- VP_IIR_FAST: transposed-form synthesis filters (floating-point tolerance, stated by north_star) ----------------
+
+RMS_TOL = 1e-4          # BASELINE.json north_star: "per-sample RMS error < 1e-4 vs reference"
+
+
+@pytest.mark.parametrize("name,prepare,params", [
+    ("default", None, dict()),
+    ("voc_1024_256", (44100.0, 1024, 1024, 768, 1024, 256), dict(lpcVoice=24, lpcSynth=5)),
+    ("cfg5_48k", (48000.0, 2048, 2048, 1536, 2048, 512), dict(lpcVoice=48, lpcPitch=48, lpcSynth=30)),
+    ("order100", None, dict(lpcVoice=100, lpcPitch=100, lpcSynth=30)),
+])
+def test_fast_iir_mode_within_tolerance_and_decisions_identical(name, prepare, params):
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S = 4
+    N = prepare[1] if prepare else 1024
+    fs = prepare[0] if prepare else FS
+    B = 14
+    x = _edge_streams(N * B)[:S] if prepare is None else _streams(S, N * B, fs=fs)
+    ref = _oracle_run(x, N, params, prepare=prepare)
+    p = BatchVocoderProcessor(**params)
+    if prepare:
+        p.prepareExplicit(fs, N, S, *prepare[2:])
+    else:
+        p.prepareToPlay(FS, N, S)
+    p.set_iir_mode("fast")
+    assert p.get_iir_mode() == "fast"
+    got = p.run(x)
+    err = got.astype(np.float64) - ref
+    rms = np.sqrt((err ** 2).mean())
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert rms < RMS_TOL, rms
+    # in practice the difference is a rare last-bit flip of the float32 cast
+    assert np.abs(err).max() <= 4e-7 * scale, (np.abs(err).max(), scale)
+    assert (got != ref).mean() < 0.02
+    # the pitch tracker (every discrete decision) is bit-identical to the oracle's
+    for s in range(S):
+        o = O.OracleStream(vocBool=0, **{k: v for k, v in params.items()})
+        if prepare:
+            o.prepare_explicit(*prepare)
+        else:
+            o.prepare_to_play(FS, N)
+        _, tr = o.run(x[s], trace=True)
+        if tr and not tr[-1]["gated"]:
+            st = p.pitch_state(s)
+            f = tr[-1]
+            assert (st["period"], st["anMarks"], st["stMarks"]) == (f["period"], f["anMarks"], f["stMarks"])
+            assert st["beta"] == f["beta"]

@@ -33,6 +33,7 @@ struct vp_handle {
     int vocWaves = 8;
     size_t vocLds = 0, pitchLds = 0;
     bool prof = false;
+    int iirMode = 0;
     struct EvPair { hipEvent_t a, b; int slot; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> evPool;
@@ -399,6 +400,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
     c.orderVoice = P.lpcVoice; c.orderSynth = P.lpcSynth; c.key = P.keyPitch;
     c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
+    c.iirFast = h->iirMode;
     c.dryOn = ((double)P.gainVoice > -59.0);                                 // PluginProcessor.cpp:226
     c.synthOn = ((double)P.gainSynth > -59.0);                               // :229
     c.gainPitch = (double)db_to_gain_f(P.gainPitch);
@@ -578,3 +580,11 @@ extern "C" int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], in
     if (reset) HIPCHK(h, hipMemset(h->d.dbg, 0, 64 * sizeof(unsigned long long)));
     return VP_OK;
 }
+
+extern "C" int vp_set_iir_mode(vp_handle *h, int mode)
+{
+    if (!h || (mode != VP_IIR_EXACT && mode != VP_IIR_FAST)) return VP_ERR_INVALID_ARG;
+    h->iirMode = mode;
+    return VP_OK;
+}
+extern "C" int vp_get_iir_mode(const vp_handle *h) { return h ? h->iirMode : VP_ERR_INVALID_ARG; }

@@ -319,6 +319,70 @@ __device__ __forceinline__ void iir_exact(XP x, YP y, int n, AP aL, int order_, 
     else iir_exact_generic(x, y, n, aL, order, i0, gmul);
 }
 
+// lane i <- lane i+1 of the whole wavefront (DPP wave_shl:1, a plain VALU move: no LDS round trip
+// like ds_bpermute); lane 63 receives 0.
+__device__ __forceinline__ double wave_shl1_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// FAST (not bit-exact) form of the same all-pole recursion, selected with vp_set_iir_mode(h, 1):
+// transposed direct form II with the state vector spread over the lanes (lane j holds s_{j+1},
+// and s_{j+65} for orders above 64):   y = g*x + s_1 ;  s_k = s_{k+1} - a_k*y  (one fma per lane).
+// The critical path per sample is readlane -> add -> fma whatever the order, against (order+1)
+// dependent operations for the exact chain.  The taps are summed oldest-first instead of
+// newest-first, so the result differs from the reference's by rounding only (~1e-16 relative per
+// operation); no decision of the algorithm depends on an IIR output.  hist[j] = y[-1-j] or nullptr.
+template <bool TWO, class XP, class YP, class AP, class HP>
+__device__ __forceinline__ void iir_fast_wave_impl(XP x, YP y, int n, AP aL, int order, HP hist, double gmul)
+{
+    const int lane = threadIdx.x & 63;
+    const int k0 = lane + 1, k1 = lane + 65;
+    const double a0 = (k0 <= order) ? aL[k0] : 0.0;
+    const double a1 = (TWO && k1 <= order) ? aL[k1] : 0.0;
+    double s0 = 0.0, s1 = 0.0;
+    if (hist) {                                   // state equivalent to the given output history
+        for (int m = 0; m < order; m++) {
+            const double hm = hist[m];
+            if (k0 + m <= order) s0 = __builtin_fma(-aL[k0 + m], hm, s0);
+            if (TWO && k1 + m <= order) s1 = __builtin_fma(-aL[k1 + m], hm, s1);
+        }
+    }
+    auto step = [&](double xi) -> double {
+        const double yy = __builtin_fma(gmul, xi, bcast_f64(s0, 0));
+        double n0 = wave_shl1_f64(s0), n1 = 0.0;
+        if (TWO) {
+            const double c = bcast_f64(s1, 0);
+            n1 = wave_shl1_f64(s1);
+            if (lane == 63) n0 = c;
+        }
+        s0 = __builtin_fma(-a0, yy, n0);
+        if (TWO) s1 = __builtin_fma(-a1, yy, n1);
+        return yy;
+    };
+    const int n8 = n & ~7;
+    for (int i = 0; i < n8; i += 8) {
+        double xv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) xv[u] = x[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) yv[u] = step(xv[u]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) y[i + u] = yv[u];           // every lane stores the same value
+    }
+    for (int i = n8; i < n; i++) y[i] = step(x[i]);
+}
+template <class XP, class YP, class AP, class HP>
+__device__ __forceinline__ void iir_fast_wave(XP x, YP y, int n, AP aL, int order_, HP hist, double gmul)
+{
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+    if (order > 64) iir_fast_wave_impl<true>(x, y, n, aL, order, hist, gmul);
+    else iir_fast_wave_impl<false>(x, y, n, aL, order, hist, gmul);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: vocoder.  VocoderProcess::process/processWindow (VocoderProcess.cpp:173-223), one workgroup
 // per stream, one wavefront per window, windows of a block taken in rounds of (waves per group).
@@ -453,7 +517,9 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
         // The chain code must run with EVERY lane of the wave active: executed under a one-lane
         // EXEC mask it is slower and, worse, chains in different waves then serialise (measured,
         // tools/ubench_iir.hip modes 1 vs 3).  Spare lanes redo the last window (identical stores).
-        if (wave == 0) {
+        if (c.iirFast) {
+            if (active) iir_fast_wave(A, B, W, aV, oV, (const lds_f64 *)nullptr, gArr[wave]);   // wave per window, lanes over taps
+        } else if (wave == 0) {
             const int wj = min(lane, nAct - 1);
             lds_f64 *wb = gArr + 8 + (size_t)wj * voc_wave_doubles(W);        // window `wj` of this round
             const lds_f64 *Aj = wb, *aVj = wb + 4 * (size_t)W + (VP_ORDER_MAX + 1);
@@ -791,7 +857,7 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
     STAMP(d, 7);
 }
 
-__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk)
+__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool fast)
 {
     // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  All 64 lanes of wave 0
     // run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
@@ -802,7 +868,8 @@ __device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const
         lds_f64 *hist = L.cum;                          // yinTemp scratch is free here
         const int nh = min(order, shift);
         for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
-        iir_exact(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
+        if (fast) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
+        else iir_exact(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
     __syncthreads();
     STAMP(d, 8);
@@ -1048,7 +1115,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
             }
             if (mode == 2) {
                 psola(g, d, L, nC, pS);
-                pitch_iir(g, d, L, nC);
+                pitch_iir(g, d, L, nC, c.iirFast != 0);
             }
             if (mode >= 1) pitch_fill_output(g, c, d, L, nC, pS, s);
             __syncthreads();
