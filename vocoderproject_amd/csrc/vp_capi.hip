@@ -416,22 +416,27 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     c.nSteps = 0;
     if (c.pitchOn && h->pStart < g.N) c.nSteps = (g.N - h->pStart + g.C - 1) / g.C;
 
-    {
-        ProfScope ps(h, st, 0);
-        hipLaunchKernelGGL(vp_k_ingest_gate, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_in);
-    }
-    if (c.nWin > 0) {
-        ProfScope ps(h, st, 1);
-        int nw = std::min(h->vocWaves, c.nWin);
-        hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(64 * nw), vp_voc_lds_bytes(g.W, nw), st, g, c, h->d);
-    }
-    if (c.nSteps > 0) {
-        ProfScope ps(h, st, 2);
-        hipLaunchKernelGGL(vp_k_pitch, dim3(g.S), dim3(512), h->pitchLds, st, g, c, h->d);
-    }
-    {
-        ProfScope ps(h, st, 3);
-        hipLaunchKernelGGL(vp_k_emit, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_out);
+    // Kernel plan: ingest+gate runs as the prologue of the first DSP kernel and emit as the epilogue of
+    // the last one (all stages are one-workgroup-per-stream); they only stand alone when no DSP kernel runs.
+    const bool runVoc = c.nWin > 0, runPitch = c.nSteps > 0;
+    if (!runVoc && !runPitch) {
+        { ProfScope ps(h, st, 0); hipLaunchKernelGGL(vp_k_ingest_gate, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_in); }
+        { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_out); }
+    } else {
+        if (runVoc) {
+            VpCall cv = c;
+            cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
+            ProfScope ps(h, st, 1);
+            int nw = std::min(h->vocWaves, c.nWin);
+            if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
+            hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(64 * nw), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
+        }
+        if (runPitch) {
+            VpCall cp = c;
+            cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
+            ProfScope ps(h, st, 2);
+            hipLaunchKernelGGL(vp_k_pitch, dim3(g.S), dim3(512), h->pitchLds, st, g, cp, h->d, d_in, d_out);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");

@@ -41,6 +41,7 @@ struct VpCall {
     int pStart, nChunk0, nSteps; // pitch chunk steps start at pStart + j*C
     int orderVoice, orderSynth, key;
     int pitchOn, vocOn, dryOn, synthOn, inplace;
+    int fuseIngest, fuseEmit;    // this launch also runs the ingest+gate prologue / the emit epilogue
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
     double gainPitch, gainVoc, gainVoice, gainSynth;   // (double) of the float gains
 };

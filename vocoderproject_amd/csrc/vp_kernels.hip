@@ -38,6 +38,8 @@ __device__ unsigned long long vp_last_stamp;
 // ------------------------------------------------------------------------------------------------
 // helpers
 
+__device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out);
+
 __device__ __forceinline__ int ring_pos(int curr, int idx, int inSize)
 {
     // MyBuffer::getVoiceSample index math (MyBuffer.cpp:152): (currCounter + idx + inSize) % inSize
@@ -84,7 +86,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // "sum_seq < gateThrSum" (gateThrSum is found on the host by bisection through the same libm
 // calls).  A tree sum T differs from the sequential one by at most ~2 n eps T, so T decides unless
 // it is within that band of the threshold, in which case one lane redoes the exact sequential sum.
-__global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in)
+__device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in)
 {
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     float *vr = d.voiceRing + (size_t)s * g.inSize;
@@ -131,6 +133,12 @@ __global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDe
         ps->nAn = 0; ps->nSt = 0;
         ps->prevPitch = 0; ps->prevPeriod = 0; ps->pitch = 0; ps->period = 0;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in)
+{
+    ingest_gate_block(g, c, d, in);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,9 +403,8 @@ __device__ __forceinline__ void iir_fast_wave(XP x, YP y, int n, AP aL, int orde
 //   D  [W] f64   eVoice (only its energy is used)
 //   r/a/aPrev for voice (101 each) and synth (31 each), energies
 
-__global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
+__device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, const VpDev &d, double *smem)
 {
-    extern __shared__ double smem[];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, nWaves = blockDim.x >> 6;
     if (!(d.gate[s * 2 + 0] && d.gate[s * 2 + 1])) return;     // :199-204, whole workgroup
@@ -554,6 +561,20 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d)
         STAMP(d, 23);
     }
     if (tid < 20) d.EeArr[(size_t)s * 20 + tid] = hist[tid];
+}
+
+// Per launch the host may fold the ingest+gate prologue and/or the emit epilogue into this kernel
+// (c.fuseIngest / c.fuseEmit): every stage is one-workgroup-per-stream, so the fusion only removes
+// kernel boundaries (~10 us each at this size), not parallelism.
+__global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    if (c.fuseIngest) ingest_gate_block(g, c, d, in);
+    vocoder_block(g, c, d, smem);
+    if (c.fuseEmit) {
+        __syncthreads();
+        emit_block(g, c, d, out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1058,10 +1079,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     return 1;
 }
 
-__global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
+__global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     PitchLds L;
     L.xs = (lds_f64 *)smem;
     L.eF = L.xs + (g.toKeep + g.F);
@@ -1136,13 +1158,17 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d)
         for (int i = tid; i < g.F; i += nt) { go[i] = L.oE[i]; gy[i] = L.yF[i]; }
     }
     STAMP(d, 11);
+    if (c.fuseEmit) {
+        __syncthreads();
+        emit_block(g, c, d, out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: emit.  addDryVoice / addSynth (MyBuffer.cpp:309-448) + fillOutputBuffer + clearOutput
 // (MyBuffer.cpp:113-133, 218-228).  out[ch] = float(((acc + dry) + synth_ch)); the consumed region of
 // the accumulator is zeroed.
-__global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out)
+__device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out)
 {
     const int s = blockIdx.x;
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
@@ -1162,4 +1188,9 @@ __global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, fl
         if (c.inplace) o[2 * g.N + i] = 0.0f;
         acc[pos] = 0.0;
     }
+}
+
+__global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out)
+{
+    emit_block(g, c, d, out);
 }
