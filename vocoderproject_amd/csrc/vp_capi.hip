@@ -306,6 +306,16 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
     const size_t ldsMax = std::min<size_t>((size_t)prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536, 160 * 1024);
+    // stage the voice window of as many consecutive chunk steps as fit comfortably (the whole block if possible)
+    g.xsSteps = 1;
+    {
+        const int stepsMax = (N + g.C - 1) / g.C;
+        for (int k = stepsMax; k >= 1; k--) {
+            VpGeom t = g;
+            t.xsSteps = k;
+            if ((size_t)(g.toKeep + F + (k - 1) * g.C) < (size_t)g.inSize && vp_pitch_lds_bytes(t) <= std::min<size_t>(ldsMax, 112 * 1024)) { g.xsSteps = k; break; }
+        }
+    }
     h->pitchLds = vp_pitch_lds_bytes(g);
     if (h->pitchLds > ldsMax) { h->lastError = "pitch frame does not fit LDS"; return VP_ERR_GEOMETRY; }
     int nw = 8;

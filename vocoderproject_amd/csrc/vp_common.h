@@ -28,7 +28,7 @@ struct VpGeom {
     int orderPitch;      // lpcPitch as read at prepare (PitchProcess.cpp:70)
     int tau0;            // floor(fS/fMax) (PitchProcess.cpp:429)
     int bufferIdxMax;    // latency + N (PitchProcess.cpp:138)
-    int pad0;
+    int xsSteps;         // chunk steps whose voice window is staged in LDS at once (pitch kernel)
     double fs, delta, yinTol;
     double gateThrSum;   // smallest sum(x^2) over the ring for which 20log10(rms) >= -60 dB
     double levEps;       // pow(10,-9)  LPC.cpp:110

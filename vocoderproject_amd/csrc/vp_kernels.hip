@@ -590,7 +590,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d,
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
 typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
-    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev;
+    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab;
     lds_state *st;
     lds_minidx *part;  // [8]
     int *ishare;       // [4] (generic pointer: used with atomicMin)
@@ -786,8 +786,9 @@ __device__ __forceinline__ void place_st_marks(const VpGeom &g, const VpCall &c,
 
 // PitchProcess::getClosestAnMarkIdx (PitchProcess.cpp:788-831); uniform, read-only.
 __device__ __forceinline__ int closest_an_mark_idx(const VpGeom &g, const lds_state *st, int stMark, int T, int nChunk,
-                                                   int pS, unsigned long long *ub)
+                                                   int pS, bool &q2hit)
 {
+    q2hit = false;
     const lds_i32 *an = st->anMarks;
     const int nAn = st->nAn;
     int lo = 0, hi = nAn;
@@ -805,16 +806,25 @@ __device__ __forceinline__ int closest_an_mark_idx(const VpGeom &g, const lds_st
         return -st->nAnMarksOv - 1;                                         // :812 -> Q3
     }
     if (idx == 0) return 0;
-    if (threadIdx.x == 0) atomicAdd(&ub[0], 1ULL);                          // Q2: anMarks[size]
+    q2hit = true;                                                            // Q2: anMarks[size]
     int stale = idx < VP_MARKS ? an[idx] : 0;
     if (stale + T - sh < avail) return idx - 1;
     if (idx - 2 >= 0) return idx - 2;
     return idx - 1;
 }
 
-// PitchProcess::psola (PitchProcess.cpp:665-741) + interp (:842-870): grains in order, the output
-// samples of one grain in parallel.
-__device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS)
+// PitchProcess::psola (PitchProcess.cpp:665-741) + interp (:842-870) in GATHER form.
+// Pass 1 (wave 0, every lane redundantly): walk the synthesis marks that are due in this chunk in
+// order and write one table entry per grain (mark, source offset in eFrame, first/last flags, the
+// grain's x-range and integer output range).  Pass 2 (all threads): every output sample adds the
+// grains that cover it, in grain order -- the order in which the reference's interp() calls
+// accumulate into outEFrame -- so there is no barrier between grains and all lanes stay busy.
+struct GrainTab {                       // lives in the yinTemp/cum scratch, free at this point
+    lds_f64 *x0, *xN;                   // [VP_MARKS]
+    lds_i32 *stMark, *srcBase, *flags, *startIdx, *stopIdx;   // [VP_MARKS]
+};
+
+__device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS, bool &qValid)
 {
     lds_state *st = L.st;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -823,57 +833,96 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
     const double *hw = d.hannTab + d.hannOff[T];
     const double beta = st->beta;
     const int nSt = st->nSt;
-    int smi = st->stMarkIdx;
+    GrainTab G;
+    G.x0 = L.dY; G.xN = L.dY + VP_MARKS;
+    G.stMark = (lds_i32 *)(L.dY + 2 * VP_MARKS); G.srcBase = G.stMark + VP_MARKS; G.flags = G.srcBase + VP_MARKS;
+    G.startIdx = G.flags + VP_MARKS; G.stopIdx = G.startIdx + VP_MARKS;
+    // xInterp[j] - stMark = (j - T)/beta is the same for every grain of the frame (:700,715,731):
+    // the 2T+1 quotients are computed once per frame, x[j] is then one exact add away.
+    if (!qValid) {
+        for (int j = tid; j < nG; j += nt) L.qtab[j] = (double)(j - T) / beta;
+        qValid = true;
+    }
     __syncthreads();
-    while (smi < nSt) {
-        const int stMark = st->stMarks[smi];
-        if (stMark - T >= (nChunk + 1) * g.C) break;                        // :685
-        int clIdx = closest_an_mark_idx(g, st, stMark, T, nChunk, pS, d.ub);
-        int clAnMark;
-        if (clIdx >= 0)
-            clAnMark = st->anMarks[clIdx];
-        else {                                                               // Q3
-            int j = st->nPrevAn - clIdx;
-            if (tid == 0) atomicAdd(&d.ub[1], 1ULL);
-            clAnMark = (j >= 0 && j < VP_MARKS) ? st->prevAnMarks[j] : 0;
+    if (tid < WAVE) {
+        // one lane per synthesis mark: the marks ascend, so the marks that are due in this chunk
+        // (:685 stMark - T < (nChunk+1) C) form a prefix of the pending ones; each lane prepares
+        // its own grain entry (closest analysis mark :692-694, x-range, output range).
+        const int smi0 = st->stMarkIdx;
+        const int smi = smi0 + tid;
+        const bool have = smi < nSt;
+        const int stMark = have ? st->stMarks[smi] : 0;
+        const bool due = have && !(stMark - T >= (nChunk + 1) * g.C);
+        const unsigned long long dueMask = __ballot(due);
+        const unsigned long long notDue = ~dueMask;
+        const int ng = notDue ? (int)__builtin_ctzll(notDue) : 64;          // length of the due prefix
+        if (tid < ng) {
+            bool q2 = false;
+            int clIdx = closest_an_mark_idx(g, st, stMark, T, nChunk, pS, q2);
+            if (q2) atomicAdd(&d.ub[0], 1ULL);
+            int clAnMark;
+            if (clIdx >= 0)
+                clAnMark = st->anMarks[clIdx];
+            else {                                                           // Q3
+                int j = st->nPrevAn - clIdx;
+                atomicAdd(&d.ub[1], 1ULL);
+                clAnMark = (j >= 0 && j < VP_MARKS) ? st->prevAnMarks[j] : 0;
+            }
+            const double dSt = (double)stMark;
+            const double x0 = dSt + L.qtab[0];                              // xInterp[0]
+            const double xN = dSt + L.qtab[nG - 1];                         // xInterp.back()
+            G.x0[tid] = x0; G.xN[tid] = xN;
+            G.stMark[tid] = stMark;
+            G.srcBase[tid] = g.toKeep + clAnMark - T;
+            G.flags[tid] = (smi == 0 ? 1 : 0) | (smi == nSt - 1 ? 2 : 0);
+            G.startIdx[tid] = max((int)floor(x0), 0);
+            G.stopIdx[tid] = min((int)ceil(xN), g.F);
         }
-        const bool first = (smi == 0);
-        const bool last = (smi == nSt - 1);
-        const int srcBase = g.toKeep + clAnMark - T;
-        const double dSt = (double)stMark;
-        const double x0 = dSt + (double)(-T) / beta;                        // xInterp[0]
-        const double xN = dSt + (double)(T) / beta;                         // xInterp.back()
-        const int startIdx = max((int)floor(x0), 0);
-        const int stopIdx = min((int)ceil(xN), g.F);
-        for (int i = startIdx + tid; i < stopIdx; i += nt) {
+        const int smiNew = smi0 + ng;
+        if (tid == 0) { st->stMarkIdx = smiNew; L.ishare[1] = ng; }
+    }
+    __syncthreads();
+    STAMP(d, 14);
+    const int ng = L.ishare[1];
+    if (ng > 0) {
+        const int lo = G.startIdx[0];                                       // marks ascend: first grain starts first
+        int hi = 0;
+        for (int q = 0; q < ng; q++) hi = max(hi, G.stopIdx[q]);
+        for (int i = lo + tid; i < hi; i += nt) {
             const double di = (double)i;
-            if (di >= x0 && di <= xN) {
-                // std::lower_bound on the strictly increasing x[j] = stMark + (j - T)/beta
+            double accv = L.oE[i];
+            for (int q = 0; q < ng; q++) {
+                if (i < G.startIdx[q] || i >= G.stopIdx[q]) continue;
+                const double x0 = G.x0[q], xN = G.xN[q];
+                if (!(di >= x0 && di <= xN)) continue;                      // :852
+                const double dSt = (double)G.stMark[q];
+                const int srcBase = G.srcBase[q], fl = G.flags[q];
+                // std::lower_bound on the strictly increasing x[j] = stMark + (j - T)/beta (:853)
                 int j = (int)ceil((di - dSt) * beta) + T;
                 j = max(0, min(j, nG - 1));
-                while (j > 0 && dSt + (double)(j - 1 - T) / beta >= di) j--;
-                while (j < nG - 1 && dSt + (double)(j - T) / beta < di) j++;
+                double xj = dSt + L.qtab[j], xjm = 0.0;
+                while (j < nG - 1 && xj < di) { j++; xj = dSt + L.qtab[j]; }
+                while (j > 0) {
+                    xjm = dSt + L.qtab[j - 1];
+                    if (xjm >= di) { j--; xj = xjm; } else break;
+                }
                 auto ys = [&](int jj) -> double {
                     int src = srcBase + jj;
                     double e = (src >= 0 && src < g.eLen) ? L.eF[src] : 0.0;
-                    bool windowed = first ? (jj >= T) : (last ? (jj < T) : true);      // :696-731
+                    bool windowed = (fl & 1) ? (jj >= T) : ((fl & 2) ? (jj < T) : true);   // :696-731 (first wins)
                     return windowed ? e * hw[jj] : e;
                 };
                 double value;
                 if (j > 0) {
-                    double xa = dSt + (double)(j - 1 - T) / beta, xb = dSt + (double)(j - T) / beta;
                     double ya = ys(j - 1), yb = ys(j);
-                    value = ya + (yb - ya) / (xb - xa) * (di - xa);
+                    value = ya + (yb - ya) / (xj - xjm) * (di - xjm);          // :860
                 } else
                     value = ys(0);
-                L.oE[i] += value;
+                accv += value;
             }
+            L.oE[i] = accv;
         }
-        __syncthreads();
-        smi++;
     }
-    __syncthreads();
-    if (tid == 0) st->stMarkIdx = smi;
     __syncthreads();
     STAMP(d, 7);
 }
@@ -1085,17 +1134,19 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     PitchLds L;
-    L.xs = (lds_f64 *)smem;
-    L.eF = L.xs + (g.toKeep + g.F);
+    lds_f64 *xsAll = (lds_f64 *)smem;                 // voice window of g.xsSteps consecutive chunk steps
+    L.xs = xsAll;
+    L.eF = L.xs + (g.toKeep + g.F + (g.xsSteps - 1) * g.C);
     L.oE = L.eF + g.eLen;
     L.yF = L.oE + g.F;
     L.dY = L.yF + g.F;
     L.cum = L.dY + (g.tauMax + 1);
     L.r = L.cum + (g.tauMax + 1);
     L.aPrev = L.r + (VP_ORDER_MAX + 1);
-    L.part = (lds_minidx *)(L.aPrev + (VP_ORDER_MAX + 1));
+    L.qtab = L.aPrev + (VP_ORDER_MAX + 1);            // [2 tauMax + 2] PSOLA quotient table
+    L.part = (lds_minidx *)(L.qtab + (2 * g.tauMax + 2));
     L.st = (lds_state *)(L.part + 8);
-    L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)L.xs)) * sizeof(int));
+    L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)xsAll)) * sizeof(int));
 
     {   // state in
         const int *src = (const int *)(d.pitch + s);
@@ -1114,10 +1165,22 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
 
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
     int pS = c.pStart, nChunk = c.nChunk0;
+    bool qValid = false;
     for (int step = 0; step < c.nSteps; step++) {
-        // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double
-        for (int j = tid; j < g.toKeep + g.F; j += nt)
-            L.xs[j] = (double)vr[ring_pos(c.currCounter, pS - g.toKeep + j, g.inSize)];
+        // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double.  Consecutive steps
+        // overlap by all but C samples, so the ring is read once per g.xsSteps steps (once per block
+        // when LDS allows) and the step's window is just an offset into that span.
+        if (step % g.xsSteps == 0) {
+            const int nst = min(g.xsSteps, c.nSteps - step);
+            const int span = g.toKeep + g.F + (nst - 1) * g.C;
+            int p0 = ring_pos(c.currCounter, pS - g.toKeep, g.inSize);
+            for (int j = tid; j < span; j += nt) {
+                int pp = p0 + j;
+                pp -= (pp >= g.inSize) ? g.inSize : 0;                  // span < inSize: one wrap at most
+                xsAll[j] = (double)vr[pp];
+            }
+        }
+        L.xs = xsAll + (step % g.xsSteps) * g.C;
         __syncthreads();
         STAMP(d, 0);
         // PitchProcess::process (:171-189): a step is [Cont of the running frame] then, when a new
@@ -1135,8 +1198,9 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
                 nC = 0;
                 mode = pitch_chunk_start_pre(g, c, d, L, pS, s);
             }
+            if (sub == 1) qValid = false;                 // a new frame: new beta / period
             if (mode == 2) {
-                psola(g, d, L, nC, pS);
+                psola(g, d, L, nC, pS, qValid);
                 pitch_iir(g, d, L, nC, c.iirFast != 0);
             }
             if (mode >= 1) pitch_fill_output(g, c, d, L, nC, pS, s);
