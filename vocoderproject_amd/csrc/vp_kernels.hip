@@ -596,39 +596,59 @@ struct PitchLds {
     int *ishare;       // [4] (generic pointer: used with atomicMin)
 };
 
-// argExt over frame positions [lo, hi) (PitchProcess.cpp:752-776), whole workgroup cooperates.
-__device__ __forceinline__ int block_arg_min(const PitchLds &L, int toKeep, int lo, int hi)
+// argExt over frame positions [lo, hi) (PitchProcess.cpp:752-776), executed by ONE wavefront with
+// all 64 lanes active.  The search windows between marks are (2 - 2 delta) T ~ 0.12 T wide (< 64
+// samples), so every lane simply repeats the reference's scan (strict '<' keeps the first minimum);
+// only the whole-frame search after an unvoiced frame is split over the lanes and reduced with
+// "first index wins" tie-breaking.
+__device__ __forceinline__ int wave_arg_min(const PitchLds &L, int toKeep, int lo, int hi)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    MinIdx m; m.v = L.xs[toKeep + lo]; m.i = lo;          // ext = sample at idxStart, always read
-    for (int i = lo + 1 + tid; i < hi; i += nt) {
-        MinIdx o; o.v = L.xs[toKeep + i]; o.i = i;
+    const lds_f64 *x = L.xs + toKeep;
+    if (hi - lo <= 128) {
+        double ext = x[lo];
+        int arg = lo;
+        int i = lo + 1;
+        for (; i + 8 <= hi; i += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = x[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (v[u] < ext) { ext = v[u]; arg = i + u; }
+        }
+        for (; i < hi; i++) { double v = x[i]; if (v < ext) { ext = v; arg = i; } }
+        return arg;
+    }
+    const int lane = threadIdx.x & 63;
+    MinIdx m; m.v = x[lo]; m.i = lo;                      // ext = sample at idxStart, always read
+    for (int i = lo + 1 + lane; i < hi; i += WAVE) {
+        MinIdx o; o.v = x[i]; o.i = i;
         m = min_first(m, o);
     }
-    m = wave_min_first(m);
-    if ((tid & 63) == 0) { L.part[tid >> 6].v = m.v; L.part[tid >> 6].i = m.i; }
-    __syncthreads();
-    MinIdx b; b.v = L.part[0].v; b.i = L.part[0].i;
-    for (int w = 1; w < (nt >> 6); w++) { MinIdx o; o.v = L.part[w].v; o.i = L.part[w].i; b = min_first(b, o); }
-    __syncthreads();
-    return b.i;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        MinIdx o;
+        o.v = __shfl_xor(m.v, off, WAVE);
+        o.i = __shfl_xor(m.i, off, WAVE);
+        m = min_first(m, o);
+    }
+    return m.i;
 }
 
 __device__ __forceinline__ int marks_back(const lds_i32 *v, int n, unsigned long long *ub)
 {
     // std::vector::back(); empty -> the reference reads the word before the heap block (0 on glibc)
     if (n > 0) return v[n - 1];
-    if (threadIdx.x == 0) atomicAdd(&ub[2], 1ULL);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&ub[2], 1ULL);
     return 0;
 }
 
-// PitchProcess::pitchMarks (PitchProcess.cpp:455-567).  All threads walk the control flow (it is
-// uniform); thread 0 owns the writes to the mark arrays; arg-min searches use the whole group.
+// PitchProcess::pitchMarks (PitchProcess.cpp:455-567), executed by wave 0 only: all 64 lanes walk
+// the (uniform) control flow and make the same stores, so there is no barrier inside.
 __device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, unsigned long long *ub)
 {
     lds_state *st = L.st;
     const int tid = threadIdx.x;
-    if (tid == 0) {
+    {
         for (int i = 0; i < st->nAn; i++) st->prevAnMarks[i] = st->anMarks[i] - g.H;   // prevAnMarks = anMarks; -= hop
         st->nPrevAn = st->nAn;
         int ov = 0;
@@ -636,18 +656,16 @@ __device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, 
         st->nAnMarksOv = ov;
         st->nAn = 0;
     }
-    __syncthreads();
     const int nPrev = st->nPrevAn, nOv = st->nAnMarksOv;
     const double pitch = st->pitch, prevPitch = st->prevPitch;
     const int period = st->period, prevPeriod = st->prevPeriod, pvp = st->prevVoicedPeriod;
     int n = 0, front = 0, back = 0;                  // uniform mirrors of anMarks.size()/front()/back()
     lds_i32 *an = st->anMarks;
-    __syncthreads();
 
-#define PUSH_BACK(val) do { int _v = (val); if (tid == 0) { if (n < VP_MARKS) an[n] = _v; if (n + 1 > 20) atomicAdd(&ub[4], 1ULL); } \
+#define PUSH_BACK(val) do { int _v = (val); { if (n < VP_MARKS) an[n] = _v; if (n + 1 > 20 && tid == 0) atomicAdd(&ub[4], 1ULL); } \
                             if (n == 0) front = _v; back = _v; if (n < VP_MARKS) n++; } while (0)
-#define PUSH_FRONT(val) do { int _v = (val); if (tid == 0) { int _k = n < VP_MARKS ? n : VP_MARKS - 1; \
-                            for (int _i = _k; _i > 0; _i--) an[_i] = an[_i - 1]; an[0] = _v; if (n + 1 > 20) atomicAdd(&ub[4], 1ULL); } \
+#define PUSH_FRONT(val) do { int _v = (val); { int _k = n < VP_MARKS ? n : VP_MARKS - 1; \
+                            for (int _i = _k; _i > 0; _i--) an[_i] = an[_i - 1]; an[0] = _v; if (n + 1 > 20 && tid == 0) atomicAdd(&ub[4], 1ULL); } \
                             front = _v; if (n < VP_MARKS) n++; } while (0)
 
     if (pitch > 1) {
@@ -660,21 +678,21 @@ __device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, 
                 int lastMark = marks_back(st->prevAnMarks, nPrev, ub);
                 int l_lim = max(lastMark + min(sw_c, (int)floor(g.delta * min(prevPeriod, period))), 0);
                 int r_lim = min(lastMark + max(sw_f, (int)ceil((2 - g.delta) * max(prevPeriod, period))), g.F);
-                t = block_arg_min(L, g.toKeep, l_lim, r_lim);
+                t = wave_arg_min(L, g.toKeep, l_lim, r_lim);
             } else
                 t = st->prevAnMarks[nPrev - nOv];
         } else {
             searchLeft = true;
-            t = block_arg_min(L, g.toKeep, 0, g.F);
+            t = wave_arg_min(L, g.toKeep, 0, g.F);
         }
         PUSH_BACK(t);
         while (back + sw_c < g.F) {                                         // :505-519
             if (back + sw_f < g.F) {
-                int m = block_arg_min(L, g.toKeep, back + sw_c, back + sw_f);
+                int m = wave_arg_min(L, g.toKeep, back + sw_c, back + sw_f);
                 PUSH_BACK(m);
             } else {
                 if (back + period < g.F) {
-                    int m = block_arg_min(L, g.toKeep, back + sw_c, g.F);
+                    int m = wave_arg_min(L, g.toKeep, back + sw_c, g.F);
                     PUSH_BACK(m);
                 }
                 break;
@@ -683,11 +701,11 @@ __device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, 
         if (searchLeft) {                                                    // :522-539
             while (front - sw_c > 0) {
                 if (front - sw_f >= 0) {
-                    int m = block_arg_min(L, g.toKeep, front - sw_f, front - sw_c);
+                    int m = wave_arg_min(L, g.toKeep, front - sw_f, front - sw_c);
                     PUSH_FRONT(m);
                 } else {
                     if (front - period >= 0) {
-                        int m = block_arg_min(L, g.toKeep, 0, front - sw_c);
+                        int m = wave_arg_min(L, g.toKeep, 0, front - sw_c);
                         PUSH_FRONT(m);
                     }
                     break;
@@ -706,9 +724,7 @@ __device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, 
     }
 #undef PUSH_BACK
 #undef PUSH_FRONT
-    __syncthreads();
-    if (tid == 0) st->nAn = n;
-    __syncthreads();
+    st->nAn = n;
 }
 
 // Notes::getClosestFreq (Notes.cpp:79-110) on the precomputed table of `key`.
@@ -1103,9 +1119,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     }
     __syncthreads();
     STAMP(d, 2);
-    pitch_marks(g, L, d.ub);
-    STAMP(d, 3);
-    if (tid < WAVE) place_st_marks(g, c, d, st);                            // all lanes redundantly (full EXEC)
+    if (tid < WAVE) {                                                        // wave 0, all lanes redundantly (full EXEC)
+        pitch_marks(g, L, d.ub);
+        STAMP(d, 3);
+        place_st_marks(g, c, d, st);
+    }
     __syncthreads();
     STAMP(d, 4);
     if (st->nAn != 0) {
