@@ -183,12 +183,12 @@ __device__ __forceinline__ double bcast_f64(double v, int src)
 // the other, so the result is bit-identical to the serial recursion; the products and the
 // coefficient update run lane-parallel.  All 64 lanes must call it (wave-uniform arguments).
 template <class RP, class AP>
-__device__ __forceinline__ void levinson_wave(RP r, AP a, int order, int aLen, double eps)
+__device__ __forceinline__ bool levinson_wave(RP r, AP a, int order, int aLen, double eps)
 {
     const int lane = threadIdx.x & 63;
     if (fabs(r[0]) < eps) {                        // :110-114 (floating abs intended)
         for (int i = lane; i < aLen; i += WAVE) a[i] = (i == 0) ? 1.0 : 0.0;
-        return;
+        return true;                               // the whole vector was rewritten
     }
     const double r0 = r[0];
     double a0 = 0.0, a1 = 0.0;                      // a[lane], a[64+lane]
@@ -222,6 +222,7 @@ __device__ __forceinline__ void levinson_wave(RP r, AP a, int order, int aLen, d
     a1 *= -1.;
     if (lane <= order) a[lane] = a0;
     if (64 + lane <= order) a[64 + lane] = a1;
+    return false;
 }
 
 // Left-to-right sum of e[i]^2, i = 0..n-1 (VocoderProcess.cpp:250), by one wavefront: lane l holds
@@ -1017,10 +1018,65 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         st->pitch = 0; st->period = 0;
         L.ishare[0] = INT_MAX;
     }
-    // computeYinTemp (PitchProcess.cpp:350-403): one lane per lag k, sum over i in order.
+    // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
     {
         const int base = g.toKeep - g.tauMax;
-        for (int k = tid; k < g.tauMax; k += nt) {
+        if ((g.C & 1) == 0) {
+            // TWO adjacent lags per lane (k = 2l, 2l+1): the lane slides one window of samples past
+            // x[i], so each element costs one new LDS value for two lags, the two accumulation chains
+            // interleave, and with the window base made even (see xsAll) every read is an aligned
+            // ds_read_b128.  (The one-lag-per-lane form below spent twice the LDS cycles, on
+            // ds_read2_b64 at half the LDS rate, and was LDS-bound at 30 us per frame.)
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) d2 lds_d2;
+            const int nPairs = (g.tauMax + 1) >> 1;
+            const int wavesY = (nPairs + WAVE - 1) / WAVE;
+#ifdef VP_DIAG_NO_YIN
+            if (false)
+#endif
+            if ((tid >> 6) < wavesY) {                                   // whole wavefronts; spare lanes redo the last pair
+                const int l = min(tid, nPairs - 1);
+                const lds_f64 *xa = L.xs + base, *xw = L.xs + base + 2 * l;
+                double accA = 0.0, accB = 0.0;
+                const int F8 = g.F & ~7;
+                double w0 = xw[0], w1 = xw[1];
+                d2 a0[4], v0[4], a1[4], v1[4];
+#define VP_Y2LOAD(A, V, I) _Pragma("unroll") for (int u = 0; u < 4; u++) { A[u] = *(const lds_d2 *)(xa + (I) + 2 * u); V[u] = *(const lds_d2 *)(xw + (I) + 2 + 2 * u); }
+#define VP_Y2COMP(A, V) { const double e_[8] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y, A[3].x, A[3].y}; \
+        const double w_[10] = {w0, w1, V[0].x, V[0].y, V[1].x, V[1].y, V[2].x, V[2].y, V[3].x, V[3].y}; \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { double dA = e_[u] - w_[u], dB = e_[u] - w_[u + 1]; accA += dA * dA; accB += dB * dB; } \
+        w0 = w_[8]; w1 = w_[9]; }
+                if (F8 > 0) { VP_Y2LOAD(a0, v0, 0) }
+                for (int i = 0; i < F8; i += 16) {
+                    const bool more1 = i + 8 < F8;
+                    if (more1) { VP_Y2LOAD(a1, v1, i + 8) }
+                    VP_Y2COMP(a0, v0)
+                    if (more1) {
+                        if (i + 16 < F8) { VP_Y2LOAD(a0, v0, i + 16) }
+                        VP_Y2COMP(a1, v1)
+                    }
+                }
+#undef VP_Y2LOAD
+#undef VP_Y2COMP
+                for (int i = F8; i < g.F; i++) {
+                    double dA = xa[i] - xw[i], dB = xa[i] - xw[i + 1];
+                    accA += dA * dA; accB += dB * dB;
+                }
+                if (tid < nPairs) {
+                    L.dY[2 * l] = accA;
+                    if (2 * l + 1 < g.tauMax) L.dY[2 * l + 1] = accB;
+                }
+            }
+        } else {
+#ifdef VP_DIAG_NO_YIN
+        if (false)
+#endif
+        // whole wavefronts only: a wave whose lags run out computes the last lag again in its spare
+        // lanes (no store) -- loops executed under a partial EXEC mask run markedly slower on this
+        // chip and slow the other waves of the group down with them (tools/ubench_iir.hip, and a
+        // 2x drop of this phase when the mask was made full)
+        for (int kk = tid; kk < ((g.tauMax + WAVE - 1) & ~(WAVE - 1)); kk += nt) {
+            const int k = min(kk, g.tauMax - 1);
             double accv = 0.0;
             const lds_f64 *xa = L.xs + base, *xb = L.xs + base + k;
             // eight elements per trip, the next trip's LDS reads issued before this trip's arithmetic
@@ -1028,7 +1084,16 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             const int F8 = g.F & ~7;
             double a0[8], b0[8], a1[8], b1[8];
 #define VP_YLOAD(A, B, I) _Pragma("unroll") for (int u = 0; u < 8; u++) { A[u] = xa[(I) + u]; B[u] = xb[(I) + u]; }
-#define VP_YCOMP(A, B) _Pragma("unroll") for (int u = 0; u < 8; u++) { double df = A[u] - B[u]; accv += df * df; }
+// differences, then squares, then the (ordered) accumulation: a dependent fp64 op stalls until
+// every VALU op issued before it has retired (tools/ubench_chain4.hip), so element-by-element
+// sub -> mul -> add pays three such stalls per element, the batched order one per add.
+#define VP_YCOMP(A, B) { double df_[8]; \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) df_[u] = A[u] - B[u]; \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) df_[u] = df_[u] * df_[u]; \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) accv += df_[u]; \
+        __builtin_amdgcn_sched_barrier(0); }
             if (F8 > 0) { VP_YLOAD(a0, b0, 0) }
             for (int i = 0; i < F8; i += 16) {
                 const bool more1 = i + 8 < F8;
@@ -1045,7 +1110,8 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
                 double df = xa[i] - xb[i];
                 accv += df * df;
             }
-            L.dY[k] = accv;
+            if (kk < g.tauMax) L.dY[k] = accv;
+        }
         }
     }
     // LPC autocorrelation of the frame (rectangular window: the products with 1.0 are exact),
@@ -1054,7 +1120,12 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     {
         const int order = g.orderPitch;
         const lds_f64 *x = L.xs + g.toKeep;
-        for (int m = nt - 1 - tid; m <= order && m >= 0; m += nt) {       // highest threads: they have no YIN lag
+#ifdef VP_DIAG_NO_AUTOCORR
+        if (false)
+#endif
+        // highest threads (they have no YIN lag), again whole wavefronts: spare lanes redo lag `order`
+        for (int m0 = nt - 1 - tid; (m0 & ~(WAVE - 1)) <= order && m0 >= 0; m0 += nt) {
+            const int m = min(m0, order);
             double sum = 0.0;
             const int cnt = g.F - m, c8 = cnt & ~7;
             const lds_f64 *xm = x + m;
@@ -1074,8 +1145,9 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 #undef VP_ALOAD
 #undef VP_ACOMP
             for (int n = c8; n < cnt; n++) sum += x[n] * xm[n];
-            L.r[m] = sum / (double)g.F;
+            if (m0 <= order) L.r[m] = sum / (double)g.F;
         }
+
     }
     __syncthreads();
     STAMP(d, 1);
@@ -1096,6 +1168,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         }
         for (int k = 1 + n8; k < g.tauMax; k++) { run += L.dY[k]; L.cum[k] = run; }
         if (lane == 0) { L.dY[0] = 1.0; L.dY[g.tauMax] = 0.0; }               // :395, guard slot (see oracle)
+    } else if (g.orderPitch < WAVE && tid >= nt - WAVE) {
+        // meanwhile, on the last wavefront: Levinson-Durbin for the frame's LPC (it needs nothing from
+        // the pitch decisions) into a scratch vector, adopted below if analysis marks exist
+        const bool z = levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
     }
     __syncthreads();
     STAMP(d, 12);
@@ -1127,7 +1204,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     __syncthreads();
     STAMP(d, 4);
     if (st->nAn != 0) {
-        if (tid < WAVE) levinson_wave(L.r, (lds_f64 *)st->a, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        if (g.orderPitch < WAVE) {                                           // coefficients are ready: adopt them (:233)
+            const int ncopy = L.ishare[2] ? VP_ORDER_MAX + 1 : g.orderPitch + 1;
+            for (int i = tid; i < ncopy; i += nt) st->a[i] = L.aPrev[i];
+        } else if (tid < WAVE)
+            levinson_wave(L.r, (lds_f64 *)st->a, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
         __syncthreads();
         STAMP(d, 5);
         const int order = g.orderPitch;
@@ -1152,9 +1233,11 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     PitchLds L;
-    lds_f64 *xsAll = (lds_f64 *)smem;                 // voice window of g.xsSteps consecutive chunk steps
+    // voice window of g.xsSteps consecutive chunk steps; shifted by one double when needed so that
+    // xs[toKeep - tauMax] (where the YIN window starts) is 16-byte aligned
+    lds_f64 *xsAll = (lds_f64 *)smem + ((g.toKeep - g.tauMax) & 1);
     L.xs = xsAll;
-    L.eF = L.xs + (g.toKeep + g.F + (g.xsSteps - 1) * g.C);
+    L.eF = (lds_f64 *)smem + (g.toKeep + g.F + (g.xsSteps - 1) * g.C + 4);   // +1 alignment pad, +2 read-ahead slack
     L.oE = L.eF + g.eLen;
     L.yF = L.oE + g.F;
     L.dY = L.yF + g.F;
@@ -1164,7 +1247,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     L.qtab = L.aPrev + (VP_ORDER_MAX + 1);            // [2 tauMax + 2] PSOLA quotient table
     L.part = (lds_minidx *)(L.qtab + (2 * g.tauMax + 2));
     L.st = (lds_state *)(L.part + 8);
-    L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)xsAll)) * sizeof(int));
+    L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
 
     {   // state in
         const int *src = (const int *)(d.pitch + s);
