@@ -944,11 +944,11 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
     STAMP(d, 7);
 }
 
-__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool fast)
+// PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
+// all 64 lanes run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
+__device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &L, int nChunk, bool fast)
 {
-    // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  All 64 lanes of wave 0
-    // run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
-    if (threadIdx.x < WAVE) {
+    {
         const int shift = nChunk * g.C, order = g.orderPitch;
         // history y[shift-1-j]; the frame starts from a zero state (yFrame is zero-filled at the
         // frame start, so reading it as history for shift > 0 is the same thing)
@@ -958,8 +958,24 @@ __device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const
         if (fast) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
         else iir_exact(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
+}
+
+__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool fast)
+{
+    if (threadIdx.x < WAVE) pitch_iir_wave(g, L, nChunk, fast);
     __syncthreads();
     STAMP(d, 8);
+}
+
+// PitchProcess::fillOutputBuffer (PitchProcess.cpp:328-342) by the calling wavefront alone
+__device__ __forceinline__ void pitch_fill_output_wave(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
+                                                       int nChunk, int pS, int s)
+{
+    double *acc = d.outAcc + (size_t)s * g.outSize;
+    for (int i = threadIdx.x & 63; i < g.C; i += WAVE) {
+        int pos = (c.outCounter + pS + i) % g.outSize;
+        acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
+    }
 }
 
 __device__ __forceinline__ void pitch_fill_output(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
@@ -997,19 +1013,30 @@ __device__ __forceinline__ bool pitch_chunk_cont_pre(const VpGeom &g, const VpCa
 
 // PitchProcess::processChunkStart (PitchProcess.cpp:203-236) up to the residual; returns
 // 0: gate closed (no output at all), 1: output only (no analysis marks: yFrame is zero), 2: full tail.
+// true when the YIN phase leaves wave 0 free (two-lags-per-lane form on at most six waves)
+__device__ __forceinline__ bool pitch_can_overlap(const VpGeom &g)
+{
+    return (g.C & 1) == 0 && ((((g.tauMax + 1) >> 1) + WAVE - 1) / WAVE) <= 6;
+}
+
+// pendingCont >= 0: the last chunk of the PREVIOUS frame (same step, PitchProcess.cpp:173-175) has had
+// its residual and PSOLA done but not yet its IIR + output; wave 0 runs them here, next to the new
+// frame's YIN on the other waves (they touch disjoint data: the old frame's outEFrame/yFrame and
+// coefficients versus xs/yinTemp), and the new frame's buffers are zeroed only afterwards.
 __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
-                                                     int pS, int s)
+                                                     int pS, int s, int pendingCont)
 {
     lds_state *st = L.st;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
+        if (pendingCont >= 0) {
+            if (tid < WAVE) { pitch_iir_wave(g, L, pendingCont, c.iirFast != 0); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+        }
         __syncthreads();
         if (tid == 0) { st->nAn = 0; st->prevPitch = 0; st->gateOpen = 0; }
         __syncthreads();
         return 0;
     }
-    for (int i = tid; i < g.eLen; i += nt) L.eF[i] = 0.0;                  // :216-218
-    for (int i = tid; i < g.F; i += nt) { L.oE[i] = 0.0; L.yF[i] = 0.0; }
     if (tid == 0) {                                                          // yin() state roll, :415-425
         st->gateOpen = 1;
         st->prevPeriod = st->period;
@@ -1021,6 +1048,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
     {
         const int base = g.toKeep - g.tauMax;
+        if (pendingCont >= 0 && !pitch_can_overlap(g)) {                    // no free wave: finish the old frame first
+            if (tid < WAVE) { pitch_iir_wave(g, L, pendingCont, c.iirFast != 0); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+            __syncthreads();
+            pendingCont = -1;
+        }
         if ((g.C & 1) == 0) {
             // TWO adjacent lags per lane (k = 2l, 2l+1): the lane slides one window of samples past
             // x[i], so each element costs one new LDS value for two lags, the two accumulation chains
@@ -1031,11 +1063,18 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             typedef __attribute__((address_space(3))) d2 lds_d2;
             const int nPairs = (g.tauMax + 1) >> 1;
             const int wavesY = (nPairs + WAVE - 1) / WAVE;
+            // waves 1..wavesY when that leaves wave 0 free for the previous frame's pending chunk
+            const int yw0 = (wavesY <= 6) ? 1 : 0;
+            if (yw0 == 1 && pendingCont >= 0 && tid < WAVE) {
+                pitch_iir_wave(g, L, pendingCont, c.iirFast != 0);
+                pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s);
+            }
 #ifdef VP_DIAG_NO_YIN
             if (false)
 #endif
-            if ((tid >> 6) < wavesY) {                                   // whole wavefronts; spare lanes redo the last pair
-                const int l = min(tid, nPairs - 1);
+            if ((tid >> 6) >= yw0 && (tid >> 6) < yw0 + wavesY) {        // whole wavefronts; spare lanes redo the last pair
+                const int ty = tid - yw0 * WAVE;
+                const int l = min(ty, nPairs - 1);
                 const lds_f64 *xa = L.xs + base, *xw = L.xs + base + 2 * l;
                 double accA = 0.0, accB = 0.0;
                 const int F8 = g.F & ~7;
@@ -1062,7 +1101,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
                     double dA = xa[i] - xw[i], dB = xa[i] - xw[i + 1];
                     accA += dA * dA; accB += dB * dB;
                 }
-                if (tid < nPairs) {
+                if (ty < nPairs) {
                     L.dY[2 * l] = accA;
                     if (2 * l + 1 < g.tauMax) L.dY[2 * l + 1] = accB;
                 }
@@ -1150,6 +1189,8 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 
     }
     __syncthreads();
+    for (int i = tid; i < g.eLen; i += nt) L.eF[i] = 0.0;                  // :216-218 (after the old frame's last chunk is out)
+    for (int i = tid; i < g.F; i += nt) { L.oE[i] = 0.0; L.yF[i] = 0.0; }
     STAMP(d, 1);
     if (tid < WAVE) {                                                        // :395-402 running sum tmp += yinTemp[k], in order
         // every lane of wave 0 runs the same chain (full EXEC); eight entries per trip are read
@@ -1286,6 +1327,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
         STAMP(d, 0);
         // PitchProcess::process (:171-189): a step is [Cont of the running frame] then, when a new
         // frame starts here, [Start]; both feed the same tail psola -> filterIIR -> fillOutputBuffer.
+        int pendingCont = -1;
         for (int sub = 0; sub < 2; sub++) {
             int mode;                       // 0 nothing, 1 output only, 2 psola + IIR + output
             int nC;
@@ -1293,11 +1335,18 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
                 if (nChunk == 0) continue;
                 nC = nChunk;
                 mode = pitch_chunk_cont_pre(g, c, d, L, nChunk, pS, s) ? 2 : 0;
+                if (mode == 2 && nChunk == g.cpf - 1) {
+                    // a new frame starts in this step: leave this chunk's IIR + output to wave 0 during
+                    // the new frame's YIN phase (pitch_chunk_start_pre)
+                    psola(g, d, L, nC, pS, qValid);
+                    pendingCont = nC;
+                    continue;
+                }
             } else {
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre(g, c, d, L, pS, s);
+                mode = pitch_chunk_start_pre(g, c, d, L, pS, s, pendingCont);
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
             if (mode == 2) {
