@@ -182,8 +182,11 @@ __device__ __forceinline__ double bcast_f64(double v, int src)
 // reference's order (i = 1..p-1, left to right) by broadcasting the per-lane products one after
 // the other, so the result is bit-identical to the serial recursion; the products and the
 // coefficient update run lane-parallel.  All 64 lanes must call it (wave-uniform arguments).
+// `scratch` (LDS, 16-byte aligned, >= 128 doubles) lets orders below 64 take a cheaper route for the
+// ordered sums: the lanes park their two products side by side in LDS and every lane then reads
+// them back in order, four steps per trip, instead of 4 v_readlane per step.
 template <class RP, class AP>
-__device__ __forceinline__ bool levinson_wave(RP r, AP a, int order, int aLen, double eps)
+__device__ __forceinline__ bool levinson_wave(RP r, AP a, int order, int aLen, double eps, lds_f64 *scratch = nullptr)
 {
     const int lane = threadIdx.x & 63;
     if (fabs(r[0]) < eps) {                        // :110-114 (floating abs intended)
@@ -191,6 +194,41 @@ __device__ __forceinline__ bool levinson_wave(RP r, AP a, int order, int aLen, d
         return true;                               // the whole vector was rewritten
     }
     const double r0 = r[0];
+    if (scratch && order < WAVE) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) d2 lds_d2;
+        lds_d2 *pr = (lds_d2 *)scratch;                 // pr[i] = { r[p-i]*a[i], r[i]*a[i] }
+        double av = 0.0;                                 // a[lane]
+        if (lane == 0) av = 1.0;
+        if (lane == 1) av = r[1] / r0;
+        const double rl = (lane <= order) ? r[lane] : 0.0;
+        for (int p = 2; p < order + 1; p++) {
+            const bool in = lane >= 1 && lane < p;
+            d2 qs;
+            qs.x = in ? r[p - lane] * av : 0.0;
+            qs.y = rl * av;
+            pr[lane] = qs;
+            double rho_a = 0.0, r_a = 0.0;
+            int i = 1;
+            for (; i + 4 <= p; i += 4) {                 // i .. i+3 < p
+                const d2 v0 = pr[i], v1 = pr[i + 1], v2 = pr[i + 2], v3 = pr[i + 3];
+                rho_a += v0.x; r_a += v0.y;
+                rho_a += v1.x; r_a += v1.y;
+                rho_a += v2.x; r_a += v2.y;
+                rho_a += v3.x; r_a += v3.y;
+            }
+            for (; i < p; i++) { const d2 v = pr[i]; rho_a += v.x; r_a += v.y; }
+            const double k = (r[p] - rho_a) / (r0 - r_a);
+            const double partner = __shfl(av, (p - lane) & 63, WAVE);     // aPrev[p - i]
+            double nv = av;
+            if (in) nv = av - k * partner;
+            if (lane == p) nv = k;
+            av = nv;
+        }
+        if (lane >= 1) av *= -1.;
+        if (lane <= order) a[lane] = av;
+        return false;
+    }
     double a0 = 0.0, a1 = 0.0;                      // a[lane], a[64+lane]
     if (lane == 0) a0 = 1.0;
     if (lane == 1) a0 = r[1] / r0;
@@ -251,6 +289,54 @@ __device__ __forceinline__ double energy_wave(EP e, int n)
 // four), x/y stream through LDS.  hist[j] = y[-1-j] (j < order) or nullptr for a zero state.
 // Taps order < k <= P run with a[k] = 0: subtracting 0*h leaves the sum unchanged (at most the
 // sign of an exact zero differs).  n must be a multiple of 4.
+// Left-to-right sums of e[i]^2 for two arrays at once (VocoderProcess.cpp:250), every lane of the
+// calling wavefront redundantly: eight entries are read ahead per trip so that only the two
+// (interleaved) chains of dependent adds remain.
+template <class EP>
+__device__ __forceinline__ void energy_pair_wave(EP e0, EP e1, int n, double &E0, double &E1)
+{
+    double r0 = 0.0, r1 = 0.0;
+    const int n8 = n & ~7;
+    for (int i = 0; i < n8; i += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a[u] = e0[i + u]; b[u] = e1[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a[u] = a[u] * a[u]; b[u] = b[u] * b[u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { r0 += a[u]; r1 += b[u]; }
+    }
+    for (int i = n8; i < n; i++) { double a = e0[i], b = e1[i]; r0 += a * a; r1 += b * b; }
+    E0 = r0; E1 = r1;
+}
+
+// VocoderProcess::filterFIR (VocoderProcess.cpp:235-251) for one window by one wavefront:
+// e[i] = a[0]*xw[i] + sum_{k=1..min(order,i)} xw[i-k]*a[k].
+template <class XP, class AP, class EP>
+__device__ __forceinline__ void fir_window8(XP xw, AP a, int order, int W, EP e, int lane)
+{
+    for (int i0 = 0; i0 < W; i0 += 8 * WAVE) {
+        double acc[8];
+        int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            idx[u] = i0 + lane + u * WAVE;
+            acc[u] = (idx[u] < W) ? a[0] * xw[idx[u]] : 0.0;             // a[0]*x*w with a[0] == 1
+        }
+        for (int k = 1; k <= order; k++) {
+            const double ak = a[k];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = idx[u] - k;
+                const double xv_ = (j >= 0 && idx[u] < W) ? xw[j] : 0.0;
+                acc[u] += xv_ * ak;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (idx[u] < W) e[idx[u]] = acc[u];
+    }
+}
+
 // v_mul_f64 / v_add_f64 with a pinned program order (asm volatile statements keep their relative
 // order).  Measured on gfx950 (tools/ubench_chain2.hip): a dependent fp64 op completes in ~8 cycles,
 // a wave can issue one every ~4, so a chain step costs 8 cycles provided the NEXT products are
@@ -452,48 +538,59 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         // lag, each lag its own left-to-right sum over n.
         if (active) {
             const int nLags = oV + 1 + oS + 1;
-            for (int q = lane; q < nLags; q += WAVE) {
+            // whole wavefronts (spare lanes redo the last lag, no store): partial-EXEC loops are slow
+            // here; eight elements are read ahead per trip, the sum stays left to right
+            for (int q0 = lane; (q0 & ~(WAVE - 1)) < nLags; q0 += WAVE) {
+                const int q = min(q0, nLags - 1);
                 const bool isV = q <= oV;
                 const int m = isV ? q : q - (oV + 1);
                 const lds_f64 *xw = isV ? B : Cc;
-                const lds_f32 *x = isV ? xv : xsy;
+                const lds_f32 *x = (isV ? xv : xsy) + m;
+                const lds_f64 *wm = win + m;
                 double sum = 0.0;
-                for (int n = 0; n < W - m; n++) sum += xw[n] * (double)x[n + m] * win[n + m];
+                const int cnt = W - m, c8 = cnt & ~7;
+                for (int n = 0; n < c8; n += 8) {
+                    double p_[8], w_[8]; float f_[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { p_[u] = xw[n + u]; f_[u] = x[n + u]; w_[u] = wm[n + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) p_[u] = p_[u] * (double)f_[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) p_[u] = p_[u] * w_[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sum += p_[u];
+                }
+                for (int n = c8; n < cnt; n++) sum += xw[n] * (double)x[n] * wm[n];
                 sum /= (double)W;
-                if (isV) rV[m] = sum; else rS[m] = sum;
+                if (q0 < nLags) { if (isV) rV[m] = sum; else rS[m] = sum; }
             }
         }
         __syncthreads();
         STAMP(d, 17);
         if (active) {                                    // whole wavefront, coefficient vector over the lanes
-            levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps);
-            levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps);
+            lds_f64 *scr = (W >= 128) ? D : (lds_f64 *)nullptr;       // eVoice is not written yet: scratch
+            levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, scr);
+            levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, scr);
         }
         __syncthreads();
         STAMP(d, 18);
 
         // filterFIR (VocoderProcess.cpp:235-251): zero history left of the window.
+        // Eight output samples per lane side by side (independent accumulators, taps in the inner
+        // position in the reference's order k = 1..order); a tap that reaches left of the window
+        // contributes an exact 0.
         if (active) {
-            for (int i = lane; i < W; i += WAVE) {
-                double e = aV[0] * B[i];                 // a[0]*x*w with a[0] == 1
-                int kmax = min(oV, i);
-                for (int k = 1; k <= kmax; k++) e += B[i - k] * aV[k];
-                D[i] = e;
-            }
+            fir_window8(B, aV, oV, W, D, lane);
         }
         __syncthreads();     // A (raw samples) is dead from here: it becomes eSynth
         if (active) {
-            for (int i = lane; i < W; i += WAVE) {
-                double e = aS[0] * Cc[i];
-                int kmax = min(oS, i);
-                for (int k = 1; k <= kmax; k++) e += Cc[i - k] * aS[k];
-                A[i] = e;
-            }
+            fir_window8(Cc, aS, oS, W, A, lane);
         }
         __syncthreads();
         STAMP(d, 19);
         if (active) {                                    // E += e[i]*e[i], left to right (:250)
-            const double Ev = energy_wave(D, W), Es = energy_wave(A, W);
+            double Ev, Es;
+            energy_pair_wave(D, A, W, Ev, Es);
             if (lane == 0) { roundE[wave] = Ev; roundE[8 + wave] = Es; }
         }
         __syncthreads();
@@ -1212,7 +1309,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     } else if (g.orderPitch < WAVE && tid >= nt - WAVE) {
         // meanwhile, on the last wavefront: Levinson-Durbin for the frame's LPC (it needs nothing from
         // the pitch decisions) into a scratch vector, adopted below if analysis marks exist
-        const bool z = levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        const bool z = levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
         if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
     }
     __syncthreads();
@@ -1285,7 +1382,8 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     L.cum = L.dY + (g.tauMax + 1);
     L.r = L.cum + (g.tauMax + 1);
     L.aPrev = L.r + (VP_ORDER_MAX + 1);
-    L.qtab = L.aPrev + (VP_ORDER_MAX + 1);            // [2 tauMax + 2] PSOLA quotient table
+    L.qtab = L.aPrev + (VP_ORDER_MAX + 1);            // [2 tauMax + 2] PSOLA quotient table (also Levinson scratch)
+    L.qtab += (int)((L.qtab - (lds_f64 *)smem) & 1);  // keep it 16-byte aligned
     L.part = (lds_minidx *)(L.qtab + (2 * g.tauMax + 2));
     L.st = (lds_state *)(L.part + 8);
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
