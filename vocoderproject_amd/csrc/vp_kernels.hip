@@ -1398,8 +1398,12 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
     if (frameLive0) {
         const double *ge = d.eFrame + (size_t)s * g.eLen, *go = d.outEFrame + (size_t)s * g.F, *gy = d.yFrame + (size_t)s * g.F;
+        // a frame is in flight: its residual, the not yet filtered part of outEFrame (chunks >= nChunk0)
+        // and the last `order` outputs (the IIR's history) are all that later chunks can read
+        const int done = c.nChunk0 * g.C;
         for (int i = tid; i < g.eLen; i += nt) L.eF[i] = ge[i];
-        for (int i = tid; i < g.F; i += nt) { L.oE[i] = go[i]; L.yF[i] = gy[i]; }
+        for (int i = done + tid; i < g.F; i += nt) L.oE[i] = go[i];
+        for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) L.yF[i] = gy[i];
     }
     __syncthreads();
 
@@ -1466,8 +1470,10 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     }
     if (nChunk != 0 && L.st->nAn != 0) {
         double *ge = d.eFrame + (size_t)s * g.eLen, *go = d.outEFrame + (size_t)s * g.F, *gy = d.yFrame + (size_t)s * g.F;
+        const int done = nChunk * g.C;                       // same ranges as the load above
         for (int i = tid; i < g.eLen; i += nt) ge[i] = L.eF[i];
-        for (int i = tid; i < g.F; i += nt) { go[i] = L.oE[i]; gy[i] = L.yF[i]; }
+        for (int i = done + tid; i < g.F; i += nt) go[i] = L.oE[i];
+        for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) gy[i] = L.yF[i];
     }
     STAMP(d, 11);
     if (c.fuseEmit) {
