@@ -99,6 +99,7 @@ struct vpo {
     double *eFrame; int eFrameLen;
     double *pAn, *pSt;             /* anWindow (ones), stWindow */
     double *psolaWindow, *periodSamples, *xInterp;
+    double *lin; int linCap;          /* linear copy of the YIN window */
     double *outEFrame, *yFrame;
     /* Notes (Notes.h:20-31) */
     double freq[VPO_NOTES_CAP + 1]; int nFreq; int notesKey;
@@ -531,15 +532,28 @@ void vpo_yin_temp_linear(const double *x, int frameLen, int tauMax, double *yinT
 
 static void compute_yin_temp(vpo *o)
 {
-    for (int k = 0; k < o->tauMax; k++) o->yinTemp[k] = 0.0;
+    /* The reference walks the ring with a two-part wrap (:369-386); the window it reads,
+     * idx in [startSample - tauMax, startSample + F + tauMax - 1), is first copied to a linear
+     * scratch here so that the inner loop over k vectorises like the reference's does
+     * (#pragma clang loop vectorize, :371).  Each yinTemp[k] is still its own left-to-right sum. */
+    const int n = o->F + o->tauMax;
+    double *lin;
+    if (n > o->linCap) {
+        free(o->lin);
+        o->lin = malloc((size_t)n * sizeof(double));
+        o->linCap = n;
+    }
+    lin = o->lin;
+    for (int j = 0; j < n; j++) lin[j] = voice_sample(o, o->pStart - o->tauMax + j);
+    double *restrict y = o->yinTemp;
+    const int tauMax = o->tauMax;
+    for (int k = 0; k < tauMax; k++) y[k] = 0.0;
     for (int i = 0; i < o->F; i++) {
-        double value_i = voice_sample(o, o->pStart + i - o->tauMax);        /* :364 */
-        int startIdx = (o->currCounter + o->pStart + i - o->tauMax + o->inSize) % o->inSize;
-        for (int k = 0; k < o->tauMax; k++) {
-            int idx = startIdx + k;                                          /* :369-386 two-part wrap */
-            if (idx >= o->inSize) idx -= o->inSize;
-            double d = value_i - o->voice[idx];
-            o->yinTemp[k] += d * d;
+        const double value_i = lin[i];                                       /* :364 */
+        const double *restrict w = lin + i;
+        for (int k = 0; k < tauMax; k++) {
+            double d = value_i - w[k];
+            y[k] += d * d;
         }
     }
     o->yinTemp[0] = 1.0;                                                     /* :395 */
@@ -940,7 +954,7 @@ void vpo_destroy(vpo *o)
     free(o->vAn); free(o->vSt); free(o->eV); free(o->eS); free(o->vOut);
     free(o->yinTemp); free(o->eFrame); free(o->pAn); free(o->pSt);
     free(o->psolaWindow); free(o->periodSamples); free(o->xInterp); free(o->outEFrame); free(o->yFrame);
-    free(o->trace);
+    free(o->trace); free(o->lin);
     free(o);
 }
 
