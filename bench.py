@@ -113,9 +113,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("VP_BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     n_gpus = world
 
     S, N, mode = args.streams, args.block, args.mode
@@ -139,14 +141,14 @@ def main():
         torch.cuda.synchronize(dev)
         p.profile_read(reset=True)
         p.profile_enable(True)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         dt_ = time.perf_counter() - t0
@@ -161,7 +163,7 @@ def main():
 
     tt = torch.tensor([dt, dt_other], dtype=torch.float64, device=dev)
     chk = y.double().abs().sum().view(1)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)          # the only collective: a checksum of the outputs
     dt, dt_other = float(tt[0].item()), float(tt[1].item())
@@ -199,7 +201,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
