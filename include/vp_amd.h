@@ -115,6 +115,17 @@ int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void 
 int vp_set_iir_mode(vp_handle *h, int mode);
 int vp_get_iir_mode(const vp_handle *h);
 
+/* How the YIN difference function (PitchProcess.cpp:350-403) and the pitch frame's LPC autocorrelation
+ * (LPC.cpp:44-97) are evaluated.
+ * VP_YIN_DIRECT (default): the reference's O(F tau) sums in its own order; decisions bit-identical.
+ * VP_YIN_FFT: Wiener-Khinchin accelerator (one forward + one inverse radix-2 FFT of >= F + tauMax points in
+ * LDS).  Values differ by ~1e-13 relative, so a threshold decision CAN differ on a near-tie; the measured
+ * rate of frames whose period differs is reported by tests/test_gpu_parity.py. */
+#define VP_YIN_DIRECT 0
+#define VP_YIN_FFT 1
+int vp_set_yin_mode(vp_handle *h, int mode);
+int vp_get_yin_mode(const vp_handle *h);
+
 /* AudioProcessor::getLatencySamples() after setLatencySamples(max(F, W)) (PluginProcessor.cpp:175,183). */
 int vp_get_latency(const vp_handle *h);
 /* N, F, H, C, W, h, samplesToKeep, latency, inSize, outSize, tauMax, chunksPerFrame

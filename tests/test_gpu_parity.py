@@ -351,3 +351,45 @@ def test_fast_iir_mode_within_tolerance_and_decisions_identical(name, prepare, p
             f = tr[-1]
             assert (st["period"], st["anMarks"], st["stMarks"]) == (f["period"], f["anMarks"], f["stMarks"])
             assert st["beta"] == f["beta"]
+
+
+# ---- VP_YIN_FFT: Wiener-Khinchin accelerator for the YIN difference function and the LPC autocorrelation ---------------
+
+def test_fft_yin_mode_decision_flip_rate_and_tolerance():
+    """the FFT form perturbs the difference function at the 1e-13 level, so a threshold
+    decision can in principle flip; measure the rate of pitch frames whose period differs from the oracle's
+    and hold the output to the north_star tolerance."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 8, 256, 96                    # one chunk per block: the tracker state is readable after every frame start
+    x = np.concatenate([_streams(5, N * B), _edge_streams(N * B)[[0, 1, 4]]])
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    p.set_yin_mode("fft")
+    assert p.get_yin_mode() == "fft"
+    os_ = [O.OracleStream(vocBool=0) for _ in range(S)]
+    for o in os_:
+        o.prepare_to_play(FS, N)
+    frames = flips = 0
+    got = np.empty((S, 2, N * B), np.float32)
+    ref = np.empty_like(got)
+    for b in range(B):
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        got[:, :, b * N:(b + 1) * N] = p.process(blk)
+        for s in range(S):
+            io = blk[s].copy()
+            os_[s].process_block(io)
+            ref[s, :, b * N:(b + 1) * N] = io[:2]
+            tr = os_[s].traces()
+            if tr and not tr[-1]["gated"]:
+                st = p.pitch_state(s)
+                frames += 1
+                flips += int(st["period"] != tr[-1]["period"] or st["anMarks"] != tr[-1]["anMarks"])
+    rate = flips / max(frames, 1)
+    err = got.astype(np.float64) - ref
+    rms = float(np.sqrt((err ** 2).mean()))
+    print(f"VP_YIN_FFT: {frames} pitch frames, {flips} with a different period/marks (rate {rate:.2e}); output RMS error {rms:.3e}")
+    assert frames > 150
+    assert rate <= 0.01, rate
+    if flips == 0:
+        assert rms < RMS_TOL and np.abs(err).max() < 1e-5

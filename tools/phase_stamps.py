@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--iir", default="exact")
+    ap.add_argument("--yin", default="direct")
     a = ap.parse_args()
     import torch
     from vocoderproject_amd import BatchVocoderProcessor
@@ -34,6 +35,7 @@ def main():
     p = BatchVocoderProcessor(pitchBool=int(a.mode != "voc"), vocBool=int(a.mode != "pitch"))
     p.prepareToPlay(44100.0, N, S)
     p.set_iir_mode(a.iir)
+    p.set_yin_mode(a.yin)
     U = 16
     x = make_streams(S, N * U, device="cuda").view(S, 3, U, N).permute(2, 0, 1, 3).contiguous()
     y = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")

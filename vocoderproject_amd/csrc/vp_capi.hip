@@ -33,7 +33,7 @@ struct vp_handle {
     int vocWaves = 8;
     size_t vocLds = 0, pitchLds = 0;
     bool prof = false;
-    int iirMode = 0;
+    int iirMode = 0, yinMode = 0;
     struct EvPair { hipEvent_t a, b; int slot; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> evPool;
@@ -317,13 +317,23 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         }
     }
     h->pitchLds = vp_pitch_lds_bytes(g);
+    // FFT accelerator: smallest power of two >= F + tauMax, if its work arrays still fit
+    g.fftLog = 0;
+    {
+        int lg = 1;
+        while ((1 << lg) < F + g.tauMax) lg++;
+        VpGeom t = g;
+        t.fftLog = lg;
+        if (h->pitchLds + vp_pitch_fft_lds_bytes(t) <= ldsMax && (1 << lg) <= 2 * F) g.fftLog = lg;   // |Ff|^2 borrows outEFrame+yFrame
+    }
     if (h->pitchLds > ldsMax) { h->lastError = "pitch frame does not fit LDS"; return VP_ERR_GEOMETRY; }
     int nw = 8;
     while (nw > 1 && vp_voc_lds_bytes(W, nw) > ldsMax) nw--;
     if (vp_voc_lds_bytes(W, nw) > ldsMax) { h->lastError = "vocoder window does not fit LDS"; return VP_ERR_GEOMETRY; }
     h->vocWaves = nw;
     h->vocLds = vp_voc_lds_bytes(W, nw);
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_vocoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vocLds));
 
     VpDev d;
@@ -345,6 +355,16 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_upload(h, &d.hannOff, hannOff));
     RC(dev_upload(h, &d.notes, notes));
     RC(dev_upload(h, &d.notesN, notesN));
+    if (g.fftLog) {
+        const int M = 1 << g.fftLog;
+        std::vector<double> twr(M / 2), twi(M / 2);
+        for (int j = 0; j < M / 2; j++) {
+            const double ang = -2.0 * 3.141592653589793238 * (double)j / (double)M;
+            twr[j] = std::cos(ang); twi[j] = std::sin(ang);
+        }
+        RC(dev_upload(h, &d.twRe, twr));
+        RC(dev_upload(h, &d.twIm, twi));
+    }
     RC(dev_alloc(h, &h->stageIn, (size_t)S * 3 * N, false));
     RC(dev_alloc(h, &h->stageOut, (size_t)S * 3 * N, false));
     {   // PitchProcess::prepare initial members (:76-85): everything 0 except beta = 1
@@ -411,6 +431,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     c.orderVoice = P.lpcVoice; c.orderSynth = P.lpcSynth; c.key = P.keyPitch;
     c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
     c.iirFast = h->iirMode;
+    c.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
     c.dryOn = ((double)P.gainVoice > -59.0);                                 // PluginProcessor.cpp:226
     c.synthOn = ((double)P.gainSynth > -59.0);                               // :229
     c.gainPitch = (double)db_to_gain_f(P.gainPitch);
@@ -445,7 +466,8 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             VpCall cp = c;
             cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
             ProfScope ps(h, st, 2);
-            hipLaunchKernelGGL(vp_k_pitch, dim3(g.S), dim3(512), h->pitchLds, st, g, cp, h->d, d_in, d_out);
+            hipLaunchKernelGGL(vp_k_pitch, dim3(g.S), dim3(512), h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0), st, g, cp,
+                               h->d, d_in, d_out);
         }
     }
     hipError_t e = hipGetLastError();
@@ -603,3 +625,12 @@ extern "C" int vp_set_iir_mode(vp_handle *h, int mode)
     return VP_OK;
 }
 extern "C" int vp_get_iir_mode(const vp_handle *h) { return h ? h->iirMode : VP_ERR_INVALID_ARG; }
+
+extern "C" int vp_set_yin_mode(vp_handle *h, int mode)
+{
+    if (!h || (mode != VP_YIN_DIRECT && mode != VP_YIN_FFT)) return VP_ERR_INVALID_ARG;
+    if (mode == VP_YIN_FFT && h->prepared && h->g.fftLog == 0) return VP_ERR_GEOMETRY;    // work arrays do not fit LDS
+    h->yinMode = mode;
+    return VP_OK;
+}
+extern "C" int vp_get_yin_mode(const vp_handle *h) { return h ? h->yinMode : VP_ERR_INVALID_ARG; }

@@ -28,6 +28,7 @@ struct VpGeom {
     int orderPitch;      // lpcPitch as read at prepare (PitchProcess.cpp:70)
     int tau0;            // floor(fS/fMax) (PitchProcess.cpp:429)
     int bufferIdxMax;    // latency + N (PitchProcess.cpp:138)
+    int fftLog;          // log2 of the FFT size of the VP_YIN_FFT accelerator (>= F + tauMax points), 0 = unavailable
     int xsSteps;         // chunk steps whose voice window is staged in LDS at once (pitch kernel)
     double fs, delta, yinTol;
     double gateThrSum;   // smallest sum(x^2) over the ring for which 20log10(rms) >= -60 dB
@@ -42,6 +43,7 @@ struct VpCall {
     int orderVoice, orderSynth, key;
     int pitchOn, vocOn, dryOn, synthOn, inplace;
     int fuseIngest, fuseEmit;    // this launch also runs the ingest+gate prologue / the emit epilogue
+    int yinFft;                  // 1: FFT accelerator for the YIN difference function + LPC autocorrelation
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
     double gainPitch, gainVoc, gainVoice, gainSynth;   // (double) of the float gains
 };
@@ -69,6 +71,7 @@ struct VpDev {
     const int *hannOff;      // [tauMax+1]
     const double *notes;     // [13][VP_NOTES_STRIDE]
     const int *notesN;       // [13]
+    const double *twRe, *twIm; // [M/2] exp(-2 pi i j / M)
     unsigned long long *ub;  // [5]
     unsigned long long *dbg; // [64] phase timers of the -DVP_STAMPS diagnostic build
 };

@@ -13,8 +13,10 @@ __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
 static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
 {
     size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + 2 * (size_t)(g.tauMax + 1) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4);
-    return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64;
+    return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
 }
+// extra dynamic LDS of the VP_YIN_FFT accelerator (re/im arrays)
+static inline size_t vp_pitch_fft_lds_bytes(const VpGeom &g) { return g.fftLog ? ((size_t)3 << g.fftLog) * sizeof(double) : 0; }   // re, im, twiddles
 static inline size_t vp_voc_lds_bytes(int W, int nWaves)
 {
     return (VP_VOC_SHARED_DOUBLES(W) + (size_t)nWaves * voc_wave_doubles(W)) * sizeof(double);

@@ -676,6 +676,55 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Radix-2 complex FFT in LDS (double), whole workgroup, M = 1 << logM points, split re/im arrays.
+// Forward: decimation in frequency, natural order in -> BIT-REVERSED order out.
+// Inverse: decimation in time, bit-reversed in -> natural out, unscaled (caller divides by M).
+// tw[j] = exp(-2 pi i j / M), j < M/2 (host libm).  No reference counterpart: this is the
+// accelerator of SURVEY.md 8f(1) (Wiener-Khinchin form of the YIN difference function and of the
+// LPC autocorrelation) and the engine of the standalone STFT kernel.
+template <class TP>
+__device__ __forceinline__ void fft_forward_dif(lds_f64 *zr, lds_f64 *zi, int logM, TP twr, TP twi)
+{
+    const int M = 1 << logM, tid = threadIdx.x, nt = blockDim.x;
+    for (int st = logM - 1; st >= 0; st--) {
+        const int half = 1 << st;
+        for (int t = tid; t < (M >> 1); t += nt) {
+            const int j = t & (half - 1);
+            const int i0 = ((t >> st) << (st + 1)) + j, i1 = i0 + half;
+            const int tj = j << (logM - 1 - st);
+            const double wr = twr[tj], wi = twi[tj];
+            const double ur = zr[i0], ui = zi[i0], vr = zr[i1], vi = zi[i1];
+            const double dr = ur - vr, di = ui - vi;
+            zr[i0] = ur + vr; zi[i0] = ui + vi;
+            zr[i1] = dr * wr - di * wi; zi[i1] = dr * wi + di * wr;
+        }
+        __syncthreads();
+    }
+}
+
+template <class TP>
+__device__ __forceinline__ void fft_inverse_dit(lds_f64 *zr, lds_f64 *zi, int logM, TP twr, TP twi)
+{
+    const int M = 1 << logM, tid = threadIdx.x, nt = blockDim.x;
+    for (int st = 0; st < logM; st++) {
+        const int half = 1 << st;
+        for (int t = tid; t < (M >> 1); t += nt) {
+            const int j = t & (half - 1);
+            const int i0 = ((t >> st) << (st + 1)) + j, i1 = i0 + half;
+            const int tj = j << (logM - 1 - st);
+            const double wr = twr[tj], wi = -twi[tj];                       // conjugate twiddle
+            const double ur = zr[i0], ui = zi[i0], xr = zr[i1], xi = zi[i1];
+            const double vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+            zr[i0] = ur + vr; zi[i0] = ui + vi;
+            zr[i1] = ur - vr; zi[i1] = ui - vi;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int bitrev(int k, int logM) { return (int)(__brev((unsigned)k) >> (32 - logM)); }
+
+// ------------------------------------------------------------------------------------------------
 // K2: pitch corrector.  PitchProcess::process (PitchProcess.cpp:166-196) for one block: one
 // workgroup per stream walks the block's chunk steps in order.
 //
@@ -688,7 +737,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d,
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
 typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
-    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab;
+    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *fft;
     lds_state *st;
     lds_minidx *part;  // [8]
     int *ishare;       // [4] (generic pointer: used with atomicMin)
@@ -1145,12 +1194,68 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
     {
         const int base = g.toKeep - g.tauMax;
-        if (pendingCont >= 0 && !pitch_can_overlap(g)) {                    // no free wave: finish the old frame first
+        if (pendingCont >= 0 && (!pitch_can_overlap(g) || c.yinFft)) {      // no free wave: finish the old frame first
             if (tid < WAVE) { pitch_iir_wave(g, L, pendingCont, c.iirFast != 0); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
             __syncthreads();
             pendingCont = -1;
         }
-        if ((g.C & 1) == 0) {
+        if (c.yinFft) {
+            // VP_YIN_FFT (accelerator, not bit-exact): with a = frame (F samples, zero padded) and
+            // b = the window of F + tauMax samples the difference function reads,
+            //   d[k] = sum a_i^2 + sum_{j=k}^{k+F-1} b_j^2 - 2 (a (x) b)[k],
+            // and with f = the frame itself (the last F samples of b): r_lpc[m] = (f (x) f)[m] / F.
+            // Forward FFTs of f and of z = a + i b, then ONE inverse FFT of conj(A) B + i |Ff|^2: the two
+            // real correlations ride in the real and imaginary parts.
+            const int M = 1 << g.fftLog;
+            lds_f64 *zr = L.fft, *zi = L.fft + M;
+            lds_f64 *T = L.oE;                                               // |Ff|^2, M <= 2F doubles (outEFrame + yFrame: free here)
+            const lds_f64 *w = L.xs + base;
+            const int nb = g.F + g.tauMax;
+            lds_f64 *twr = zi + M, *twi = twr + (M >> 1);                     // twiddles staged in LDS once per frame
+            for (int j = tid; j < (M >> 1); j += nt) { twr[j] = d.twRe[j]; twi[j] = d.twIm[j]; }
+            for (int j = tid; j < M; j += nt) { zr[j] = (j < g.F) ? w[g.tauMax + j] : 0.0; zi[j] = 0.0; }
+            __syncthreads();
+            fft_forward_dif(zr, zi, g.fftLog, (const lds_f64 *)twr, (const lds_f64 *)twi);
+            for (int j = tid; j < M; j += nt) T[j] = zr[j] * zr[j] + zi[j] * zi[j];    // same (bit-reversed) positions as below
+            __syncthreads();
+            for (int j = tid; j < M; j += nt) { zr[j] = (j < g.F) ? w[j] : 0.0; zi[j] = (j < nb) ? w[j] : 0.0; }
+            // exclusive prefix sums of b_j^2 (three entries per thread, wave + group scan) into eF scratch
+            lds_f64 *P = L.eF;
+            {
+                const int per = (nb + nt - 1) / nt;
+                const int j0 = tid * per;
+                double loc = 0.0;
+                for (int u = 0; u < per; u++) { const int j = j0 + u; if (j < nb) { const double v = w[j]; loc += v * v; } }
+                double inc = loc;
+                const int lane = tid & 63;
+                for (int off = 1; off < WAVE; off <<= 1) { const double o = __shfl_up(inc, off, WAVE); if (lane >= off) inc += o; }
+                if (lane == 63) L.dY[tid >> 6] = inc;                       // wave totals (dY is free until the scan is read)
+                __syncthreads();
+                double wbase = 0.0;
+                for (int q = 0; q < (tid >> 6); q++) wbase += L.dY[q];
+                double run = wbase + inc - loc;                              // exclusive prefix of this thread
+                for (int u = 0; u < per; u++) { const int j = j0 + u; if (j <= nb) { P[j] = run; if (j < nb) { const double v = w[j]; run += v * v; } } }
+                if (tid == nt - 1 && j0 + per <= nb) P[nb] = run;
+            }
+            __syncthreads();
+            fft_forward_dif(zr, zi, g.fftLog, (const lds_f64 *)twr, (const lds_f64 *)twi);
+            for (int k = tid; k <= (M >> 1); k += nt) {                      // spectra in bit-reversed positions
+                const int pk = bitrev(k, g.fftLog), pm = bitrev((M - k) & (M - 1), g.fftLog);
+                const double zkr = zr[pk], zki = zi[pk], zmr = zr[pm], zmi = zi[pm];
+                const double Ar = 0.5 * (zkr + zmr), Ai = 0.5 * (zki - zmi);
+                const double Br = 0.5 * (zki + zmi), Bi = -0.5 * (zkr - zmr);
+                const double c1r = Ar * Br + Ai * Bi, c1i = Ar * Bi - Ai * Br;      // conj(A) B
+                const double c2 = T[pk];                                           // |Ff|^2 (== T[pm])
+                zr[pk] = c1r; zi[pk] = c1i + c2;
+                zr[pm] = c1r; zi[pm] = c2 - c1i;
+            }
+            __syncthreads();
+            fft_inverse_dit(zr, zi, g.fftLog, (const lds_f64 *)twr, (const lds_f64 *)twi);
+            const double invM = 1.0 / (double)M;
+            const double E0 = P[g.F] - P[0];
+            for (int k = tid; k < g.tauMax; k += nt) L.dY[k] = E0 + (P[k + g.F] - P[k]) - 2.0 * (zr[k] * invM);
+            for (int m = tid; m <= g.orderPitch; m += nt) L.r[m] = (zi[m] * invM) / (double)g.F;
+        } else if ((g.C & 1) == 0) {
             // TWO adjacent lags per lane (k = 2l, 2l+1): the lane slides one window of samples past
             // x[i], so each element costs one new LDS value for two lags, the two accumulation chains
             // interleave, and with the window base made even (see xsAll) every read is an aligned
@@ -1259,6 +1364,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 #ifdef VP_DIAG_NO_AUTOCORR
         if (false)
 #endif
+        if (!c.yinFft)
         // highest threads (they have no YIN lag), again whole wavefronts: spare lanes redo lag `order`
         for (int m0 = nt - 1 - tid; (m0 & ~(WAVE - 1)) <= order && m0 >= 0; m0 += nt) {
             const int m = min(m0, order);
@@ -1387,6 +1493,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
     L.part = (lds_minidx *)(L.qtab + (2 * g.tauMax + 2));
     L.st = (lds_state *)(L.part + 8);
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
+    L.fft = (lds_f64 *)(L.st + 1) + 8;                // [2 << fftLog] only when launched with the FFT extension
 
     {   // state in
         const int *src = (const int *)(d.pitch + s);

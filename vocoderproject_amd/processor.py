@@ -79,6 +79,8 @@ def load_library():
     L.vp_kernel_slot_name.restype = C.c_char_p
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
     L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
+    L.vp_set_yin_mode.argtypes = [vp, C.c_int]
+    L.vp_get_yin_mode.argtypes = [vp]
     L.vp_set_iir_mode.argtypes = [vp, C.c_int]
     L.vp_get_iir_mode.argtypes = [vp]
     L.vp_error_string.argtypes = [C.c_int]
@@ -140,6 +142,13 @@ class BatchVocoderProcessor:
     def set_iir_mode(self, mode):
         """"exact" (default, bit-identical to the reference's summation order) or "fast" (VP_IIR_FAST)."""
         self._chk(self.L.vp_set_iir_mode(self.h, {"exact": 0, "fast": 1}[mode] if isinstance(mode, str) else int(mode)))
+
+    def set_yin_mode(self, mode):
+        """"direct" (default, reference summation order) or "fft" (VP_YIN_FFT accelerator)."""
+        self._chk(self.L.vp_set_yin_mode(self.h, {"direct": 0, "fft": 1}[mode] if isinstance(mode, str) else int(mode)))
+
+    def get_yin_mode(self):
+        return "fft" if self.L.vp_get_yin_mode(self.h) == 1 else "direct"
 
     def get_iir_mode(self):
         return "fast" if self.L.vp_get_iir_mode(self.h) == 1 else "exact"
