@@ -86,6 +86,27 @@ def cpu_baseline(mode, N, seconds_target=12.0):
                       f"{dt:.1f} s wall"}
 
 
+def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
+    """Standalone STFT->iSTFT kernel (Hann, radix-2 FFT, iFFT, OLA): NO reference counterpart, reported apart
+    from the metric."""
+    import torch
+    from vocoderproject_amd import StftRoundTrip
+    st = StftRoundTrip(S, T, F, hop, device=dev.index or 0)
+    x = torch.randn((S, T), dtype=torch.float32, device=dev) * 0.1
+    y = torch.empty_like(x)
+    for _ in range(3):
+        st(x, y)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st(x, y)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    frames = S * st.n_frames
+    return {"frames_per_s": frames / dt, "note": "standalone STFT round trip 1024/256, fp64 radix-2 FFT in LDS; no reference counterpart",
+            "hbm_gbs": (2 * S * T * 4 + 2 * frames * F * 4) / dt / 1e9}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +219,7 @@ def main():
             "checksum": float(chk.item()),
             f"value_{other}_mode": frames_per_step_gpu * k2 * n_gpus / dt_other,
         }
+        out["stft_kernel"] = stft_figure(dev, S)
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
         print(json.dumps(out))

@@ -157,6 +157,16 @@ int vp_read_ub_counters(vp_handle *h, long out[5]);
  * the product build. */
 int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
 
+/* Standalone STFT round trip: sqrt-Hann window, batched radix-2 FFT, inverse FFT, overlap-add (frame_len a
+ * power of two <= 4096, hop dividing it).  NO reference counterpart (the reference contains no FFT, SURVEY.md
+ * section 0): it is the STFT-shaped kernel BASELINE.json's north_star lists, reported on its own by bench.py.
+ * d_in/d_out: device float32 [n_streams][n_samples]; d_mag (optional): [n_streams][frames][frame_len/2+1]. */
+typedef struct vp_stft vp_stft;
+int vp_stft_create(int device, int n_streams, int n_samples, int frame_len, int hop, vp_stft **out);
+int vp_stft_destroy(vp_stft *p);
+int vp_stft_num_frames(const vp_stft *p);
+int vp_stft_roundtrip(vp_stft *p, const float *d_in, float *d_out, float *d_mag, void *hip_stream);
+
 const char *vp_error_string(int code);
 const char *vp_last_error(const vp_handle *h);
 int vp_abi_version(void);

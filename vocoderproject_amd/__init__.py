@@ -4,4 +4,4 @@ Product code: csrc/ (HIP kernels + C ABI, built into libvp_amd.so), processor.py
 reference's plugin surface), synth.py (synthetic streams), dist.py (stream sharding across ranks).
 Nothing here imports oracle/.
 """
-from .processor import BatchVocoderProcessor, VpError, load_library, PARAM_IDS, KEYS  # noqa: F401
+from .processor import BatchVocoderProcessor, StftRoundTrip, VpError, load_library, PARAM_IDS, KEYS  # noqa: F401

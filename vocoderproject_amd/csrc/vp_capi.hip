@@ -634,3 +634,69 @@ extern "C" int vp_set_yin_mode(vp_handle *h, int mode)
     return VP_OK;
 }
 extern "C" int vp_get_yin_mode(const vp_handle *h) { return h ? h->yinMode : VP_ERR_INVALID_ARG; }
+
+// ---- standalone STFT round trip (no reference counterpart; see vp_k_stft_frames) ------------------------------
+struct vp_stft {
+    int device, logF, F, hop, S, T, nFrames;
+    double *win = nullptr, *twRe = nullptr, *twIm = nullptr;
+    float *frames = nullptr;
+    float scale;
+};
+
+extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int frame_len, int hop, vp_stft **out)
+{
+    if (!out || n_streams <= 0 || frame_len < 8 || hop <= 0 || n_samples < frame_len) return VP_ERR_INVALID_ARG;
+    int lg = 0;
+    while ((1 << lg) < frame_len) lg++;
+    if ((1 << lg) != frame_len || lg > 12 || frame_len % hop) return VP_ERR_GEOMETRY;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    vp_stft *p = new vp_stft();
+    p->device = device; p->logF = lg; p->F = frame_len; p->hop = hop; p->S = n_streams; p->T = n_samples;
+    p->nFrames = (n_samples - frame_len) / hop + 1;
+    std::vector<double> w(frame_len), tr(frame_len / 2), ti(frame_len / 2);
+    double sumsq = 0;                                             // sum over one hop grid of w^2 (constant for periodic Hann)
+    for (int i = 0; i < frame_len; i++) w[i] = std::sqrt(0.5 - 0.5 * std::cos(2.0 * 3.141592653589793238 * i / frame_len));
+    for (int i = 0; i < frame_len; i += hop) sumsq += w[i] * w[i];
+    p->scale = (float)(1.0 / sumsq);
+    for (int j = 0; j < frame_len / 2; j++) {
+        double a = -2.0 * 3.141592653589793238 * j / frame_len;
+        tr[j] = std::cos(a); ti[j] = std::sin(a);
+    }
+    bool ok = hipMalloc(&p->win, w.size() * 8) == hipSuccess && hipMalloc(&p->twRe, tr.size() * 8) == hipSuccess &&
+              hipMalloc(&p->twIm, ti.size() * 8) == hipSuccess &&
+              hipMalloc(&p->frames, (size_t)n_streams * p->nFrames * frame_len * sizeof(float)) == hipSuccess;
+    if (ok) ok = hipMemcpy(p->win, w.data(), w.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(p->twRe, tr.data(), tr.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(p->twIm, ti.data(), ti.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { (void)hipFree(p->win); (void)hipFree(p->twRe); (void)hipFree(p->twIm); (void)hipFree(p->frames); delete p; return VP_ERR_OOM; }
+    *out = p;
+    return VP_OK;
+}
+
+extern "C" int vp_stft_destroy(vp_stft *p)
+{
+    if (!p) return VP_ERR_INVALID_ARG;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(p->win); (void)hipFree(p->twRe); (void)hipFree(p->twIm); (void)hipFree(p->frames);
+    delete p;
+    return VP_OK;
+}
+
+extern "C" int vp_stft_num_frames(const vp_stft *p) { return p ? p->nFrames : VP_ERR_INVALID_ARG; }
+
+// d_in, d_out: device float32 [S][T]; d_mag: optional device float32 [S][nFrames][F/2+1] (or NULL)
+extern "C" int vp_stft_roundtrip(vp_stft *p, const float *d_in, float *d_out, float *d_mag, void *hip_stream)
+{
+    if (!p || !d_in || !d_out) return VP_ERR_INVALID_ARG;
+    if (hipSetDevice(p->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t lds = (size_t)3 * p->F * sizeof(double);
+    hipLaunchKernelGGL(vp_k_stft_frames, dim3(p->nFrames, p->S), dim3(256), lds, st, d_in, p->frames, d_mag, p->win, p->twRe, p->twIm,
+                       p->T, p->nFrames, p->logF, p->hop);
+    hipLaunchKernelGGL(vp_k_stft_ola, dim3(std::min(64, (p->T + 255) / 256), p->S), dim3(256), 0, st, p->frames, d_out, p->T, p->nFrames,
+                       p->F, p->hop, p->scale);
+    return hipGetLastError() == hipSuccess ? VP_OK : VP_ERR_HIP;
+}

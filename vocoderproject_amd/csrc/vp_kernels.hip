@@ -1619,3 +1619,48 @@ __global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, fl
 {
     emit_block(g, c, d, out);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Standalone STFT round trip (NO reference counterpart -- the reference has no FFT, SURVEY.md section 0;
+// this is the "Hann windowing, batched radix-2 FFT/iFFT, overlap-add" kernel BASELINE.json's
+// north_star names, reported separately).  One workgroup per (stream, frame): sqrt-Hann analysis
+// window, forward FFT, [identity spectral stage, optional magnitude dump], inverse FFT, sqrt-Hann
+// synthesis window -> frame scratch; a second kernel overlap-adds in gather form (deterministic).
+__global__ __launch_bounds__(256) void vp_k_stft_frames(const float *__restrict__ in, float *__restrict__ frames,
+                                                        float *__restrict__ mag, const double *__restrict__ win,
+                                                        const double *__restrict__ twRe, const double *__restrict__ twIm,
+                                                        int nSamples, int nFrames, int logF, int hop)
+{
+    extern __shared__ double smem[];
+    const int F = 1 << logF, tid = threadIdx.x, nt = blockDim.x;
+    const int s = blockIdx.y, f = blockIdx.x;
+    lds_f64 *zr = (lds_f64 *)smem, *zi = zr + F, *twr = zi + F, *twi = twr + (F >> 1);
+    const float *x = in + (size_t)s * nSamples + (size_t)f * hop;
+    for (int j = tid; j < (F >> 1); j += nt) { twr[j] = twRe[j]; twi[j] = twIm[j]; }
+    for (int j = tid; j < F; j += nt) { zr[j] = (double)x[j] * win[j]; zi[j] = 0.0; }
+    __syncthreads();
+    fft_forward_dif(zr, zi, logF, (const lds_f64 *)twr, (const lds_f64 *)twi);
+    if (mag) {                                                       // |X[k]|, k <= F/2 (natural order)
+        float *m = mag + ((size_t)s * nFrames + f) * ((F >> 1) + 1);
+        for (int k = tid; k <= (F >> 1); k += nt) { const int p = bitrev(k, logF); m[k] = (float)sqrt(zr[p] * zr[p] + zi[p] * zi[p]); }
+    }
+    fft_inverse_dit(zr, zi, logF, (const lds_f64 *)twr, (const lds_f64 *)twi);
+    float *o = frames + ((size_t)s * nFrames + f) * F;
+    const double invF = 1.0 / (double)F;
+    for (int j = tid; j < F; j += nt) o[j] = (float)(zr[j] * invF * win[j]);
+}
+
+__global__ __launch_bounds__(256) void vp_k_stft_ola(const float *__restrict__ frames, float *__restrict__ out, int nSamples,
+                                                     int nFrames, int F, int hop, float scale)
+{
+    const int s = blockIdx.y;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nSamples; t += gridDim.x * blockDim.x) {
+        const int fhi = min(nFrames - 1, t / hop), flo = max(0, (t - F + hop) / hop);
+        float acc = 0.f;
+        for (int f = flo; f <= fhi; f++) {
+            const int j = t - f * hop;
+            if (j >= 0 && j < F) acc += frames[((size_t)s * nFrames + f) * F + j];
+        }
+        out[(size_t)s * nSamples + t] = acc * scale;
+    }
+}

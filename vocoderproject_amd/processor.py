@@ -83,6 +83,10 @@ def load_library():
     L.vp_get_yin_mode.argtypes = [vp]
     L.vp_set_iir_mode.argtypes = [vp, C.c_int]
     L.vp_get_iir_mode.argtypes = [vp]
+    L.vp_stft_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.vp_stft_destroy.argtypes = [vp]
+    L.vp_stft_num_frames.argtypes = [vp]
+    L.vp_stft_roundtrip.argtypes = [vp, fp, fp, fp, C.c_void_p]
     L.vp_error_string.argtypes = [C.c_int]
     L.vp_error_string.restype = C.c_char_p
     L.vp_last_error.argtypes = [vp]
@@ -238,3 +242,38 @@ class BatchVocoderProcessor:
         n = (C.c_long * KERNEL_SLOTS)()
         self._chk(self.L.vp_profile_read(self.h, ms, n, int(bool(reset))))
         return {self.L.vp_kernel_slot_name(i).decode(): (ms[i], n[i]) for i in range(KERNEL_SLOTS)}
+
+
+class StftRoundTrip:
+    """Standalone batched STFT -> iSTFT (no reference counterpart; see include/vp_amd.h vp_stft_*)."""
+
+    def __init__(self, n_streams, n_samples, frame_len=1024, hop=256, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.vp_stft_create(int(device), int(n_streams), int(n_samples), int(frame_len), int(hop), C.byref(h))
+        if rc:
+            raise VpError(rc, self.L.vp_error_string(rc).decode())
+        self.h, self.S, self.T, self.F, self.hop = h, n_streams, n_samples, frame_len, hop
+        self.n_frames = self.L.vp_stft_num_frames(h)
+
+    def __call__(self, d_in, d_out, d_mag=None, stream=None):
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and tuple(d_in.shape) == (self.S, self.T) and d_in.is_contiguous()
+        assert d_out.is_cuda and tuple(d_out.shape) == (self.S, self.T) and d_out.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        rc = self.L.vp_stft_roundtrip(self.h, d_in.data_ptr(), d_out.data_ptr(), d_mag.data_ptr() if d_mag is not None else None,
+                                      C.c_void_p(stream))
+        if rc:
+            raise VpError(rc, self.L.vp_error_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vp_stft_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
