@@ -65,6 +65,7 @@ struct VpDev {
     VpPitchState *pitch;
     double *eFrame, *outEFrame, *yFrame;
     double *EeArr;
+    double *hImp;            // [S][64] impulse response of the in-flight pitch frame's 1/A(z) (block-form IIR)
     const double *vocWin;    // [W]  anWindow == stWindow ("sine", VocoderProcess.cpp:125-129)
     const double *pitchStWin;// [F]
     const double *hannTab;   // hann(2T+1) for T = 1..tauMax, concatenated
