@@ -65,7 +65,7 @@ def cpu_baseline(mode, N, seconds_target=12.0):
     o.run(x1)
     per_block = (time.perf_counter() - t) / 8
     blocks = 128
-    reps = int(max(1, min(64, round(seconds_target / max(per_block * blocks, 1e-6)))))
+    reps = int(max(1, min(512, round(seconds_target / max(per_block * blocks, 1e-6)))))
     n_streams = cores
     x = np.ascontiguousarray(make_streams(n_streams, N * blocks).numpy())
 
@@ -84,6 +84,19 @@ def cpu_baseline(mode, N, seconds_target=12.0):
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_streams} streams x {blocks} blocks of {N} samples, mode={mode}, one oracle stream per thread, "
                       f"{dt:.1f} s wall"}
+
+
+def measured_traffic(mode, S, N, iir):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this very command); None when the
+    configuration being benched is not the one that was profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        key = f"{mode}/S{S}/N{N}/{iir}"
+        return t["per_launch_bytes"].get(key)
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
@@ -118,6 +131,8 @@ def main():
     ap.add_argument("--iir", default="fast", choices=["fast", "exact"],
                     help="arithmetic of the two synthesis IIRs: 'fast' (VP_IIR_FAST, tolerance-tested) is the measured "
                          "configuration; 'exact' (bit-identical to the oracle) is timed beside it as value_exact_mode")
+    ap.add_argument("--single-mode", action="store_true",
+                    help="do not time the other IIR mode or the STFT kernel (for profiler runs: one kernel population)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -179,7 +194,9 @@ def main():
     # secondary figure first (shorter), then THE timed region: W warmup steps, exactly K timed steps
     other = "exact" if args.iir == "fast" else "fast"
     k2 = max(10, args.steps // 4)
-    dt_other, _ = timed(other, k2, max(2, args.warmup // 4))
+    dt_other = float("nan")
+    if not args.single_mode:
+        dt_other, _ = timed(other, k2, max(2, args.warmup // 4))
     dt, prof = timed(args.iir, args.steps, args.warmup)
 
     tt = torch.tensor([dt, dt_other], dtype=torch.float64, device=dev)
@@ -217,9 +234,11 @@ def main():
                          "note": "path is fp64-VALU/latency-bound (DESIGN.md); HBM fraction is reported as the contract asks"},
             "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if v[1]},
             "checksum": float(chk.item()),
-            f"value_{other}_mode": frames_per_step_gpu * k2 * n_gpus / dt_other,
+            f"value_{other}_mode": (frames_per_step_gpu * k2 * n_gpus / dt_other) if dt_other == dt_other else None,
         }
-        out["stft_kernel"] = stft_figure(dev, S)
+        if not args.single_mode:
+            out["stft_kernel"] = stft_figure(dev, S)
+        out["roofline"]["traffic"] = measured_traffic(mode, S, N, args.iir)
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
         print(json.dumps(out))
