@@ -58,18 +58,6 @@ __device__ __forceinline__ MinIdx min_first(MinIdx a, MinIdx b)
     return a;
 }
 
-__device__ __forceinline__ MinIdx wave_min_first(MinIdx m)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        MinIdx o;
-        o.v = __shfl_down(m.v, off, WAVE);
-        o.i = __shfl_down(m.i, off, WAVE);
-        m = min_first(m, o);
-    }
-    return m;
-}
-
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -140,32 +128,6 @@ __global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDe
 {
     ingest_gate_block(g, c, d, in);
 }
-
-// ------------------------------------------------------------------------------------------------
-// Levinson-Durbin, LPC.cpp:107-148, executed by ONE lane on LDS arrays (a, aPrev sized aLen).
-__device__ void levinson_durbin(const double *r, double *a, double *aPrev, int order, int aLen, double eps)
-{
-    if (fabs(r[0]) < eps) {                        // :110-114 (floating abs intended)
-        for (int i = 0; i < aLen; i++) a[i] = 0.0;
-        a[0] = 1.0;
-        return;
-    }
-    a[0] = 1.0;
-    a[1] = r[1] / r[0];
-    for (int p = 2; p < order + 1; p++) {
-        for (int j = 1; j < p; j++) aPrev[j] = a[j];
-        double rho_a = 0.0, r_a = 0.0;
-        for (int i = 1; i < p; i++) {
-            rho_a += r[p - i] * a[i];
-            r_a += r[i] * a[i];
-        }
-        double k = (r[p] - rho_a) / (r[0] - r_a);
-        for (int i = 1; i < p; i++) a[i] = aPrev[i] - k * aPrev[p - i];
-        a[p] = k;
-    }
-    for (int i = 1; i < order + 1; i++) a[i] *= -1.;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Wave-uniform broadcast of a double held by lane `src` (src is wave-uniform): two v_readlane_b32.
@@ -263,32 +225,6 @@ __device__ __forceinline__ bool levinson_wave(RP r, AP a, int order, int aLen, d
     return false;
 }
 
-// Left-to-right sum of e[i]^2, i = 0..n-1 (VocoderProcess.cpp:250), by one wavefront: lane l holds
-// the squares of i = 64 j + l; they are folded into the running sum in index order by broadcast.
-// All 64 lanes must call it; every lane returns the sum.
-template <class EP>
-__device__ __forceinline__ double energy_wave(EP e, int n)
-{
-    const int lane = threadIdx.x & 63;
-    double E = 0.0;
-    for (int j0 = 0; j0 < n; j0 += WAVE) {
-        const int i = j0 + lane;
-        const double v = (i < n) ? e[i] : 0.0;
-        const double sq = v * v;
-        const int m = min(WAVE, n - j0);
-        for (int l = 0; l < m; l++) E += bcast_f64(sq, l);
-    }
-    return E;
-}
-
-// Exact all-pole recursion y[i] = g*x[i] - sum_{k=1..order} y[i-k]*a[k], the sum taken in the
-// reference's order k = 1, 2, ... (VocoderProcess.cpp:277-286, PitchProcess.cpp:307-322), by ONE lane.
-// The chain of (order+1) dependent double operations per sample is irreducible without changing
-// the rounding, so the job here is to make every step cost one VALU issue: coefficients and the
-// last P outputs live in registers (static indices: four samples per trip, history shifted by
-// four), x/y stream through LDS.  hist[j] = y[-1-j] (j < order) or nullptr for a zero state.
-// Taps order < k <= P run with a[k] = 0: subtracting 0*h leaves the sum unchanged (at most the
-// sign of an exact zero differs).  n must be a multiple of 4.
 // Left-to-right sums of e[i]^2 for two arrays at once (VocoderProcess.cpp:250), every lane of the
 // calling wavefront redundantly: eight entries are read ahead per trip so that only the two
 // (interleaved) chains of dependent adds remain.
@@ -1467,22 +1403,27 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         const int lane = tid;
         double run = 0.0;
         const int n8 = (g.tauMax - 1) & ~7;
-        for (int k0 = 1; k0 < 1 + n8; k0 += 8) {
-            double v[8], cs[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = L.dY[k0 + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { run += v[u]; cs[u] = run; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) L.cum[k0 + u] = cs[u];
+        // ping-pong register sets: the next eight entries are requested before the current eight are
+        // chained, so the LDS latency overlaps the dependent adds
+        double va[8], vb[8];
+#define VP_CLOAD(V, K) _Pragma("unroll") for (int u = 0; u < 8; u++) V[u] = L.dY[(K) + u];
+#define VP_CSUM(V, K) { double cs_[8]; _Pragma("unroll") for (int u = 0; u < 8; u++) { run += V[u]; cs_[u] = run; } \
+                        _Pragma("unroll") for (int u = 0; u < 8; u++) L.cum[(K) + u] = cs_[u]; }
+        const int kEnd = 1 + n8;
+        if (n8 > 0) { VP_CLOAD(va, 1) }
+        for (int k0 = 1; k0 < kEnd; k0 += 16) {
+            const bool more1 = k0 + 8 < kEnd;
+            if (more1) { VP_CLOAD(vb, k0 + 8) }
+            VP_CSUM(va, k0)
+            if (more1) {
+                if (k0 + 16 < kEnd) { VP_CLOAD(va, k0 + 16) }
+                VP_CSUM(vb, k0 + 8)
+            }
         }
+#undef VP_CLOAD
+#undef VP_CSUM
         for (int k = 1 + n8; k < g.tauMax; k++) { run += L.dY[k]; L.cum[k] = run; }
         if (lane == 0) { L.dY[0] = 1.0; L.dY[g.tauMax] = 0.0; }               // :395, guard slot (see oracle)
-    } else if (g.orderPitch < WAVE && tid >= nt - WAVE) {
-        // meanwhile, on the last wavefront: Levinson-Durbin for the frame's LPC (it needs nothing from
-        // the pitch decisions) into a scratch vector, adopted below if analysis marks exist
-        const bool z = levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
-        if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
     }
     __syncthreads();
     STAMP(d, 12);
@@ -1510,14 +1451,20 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         pitch_marks(g, L, d.ub);
         STAMP(d, 3);
         place_st_marks(g, c, d, st);
-    } else if (tid >= nt - WAVE && (g.C & 63) == 0 && g.orderPitch < WAVE) {
-        // meanwhile, last wavefront: impulse response of the new 1/A(z) for the block-form IIR
-        // (cum[] is dead after the normalisation; layout as in pitch_iir_wave)
-        lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
-        const int lane = tid & 63;
-        hpad[lane] = 0.0;
-        xp[lane] = (lane == 0) ? 1.0 : 0.0;
-        iir_fast_wave(xp, hpad + WAVE, WAVE, (const lds_f64 *)L.aPrev, g.orderPitch, (const lds_f64 *)nullptr, 1.0);
+    } else if (tid >= nt - WAVE && g.orderPitch < WAVE) {
+        // meanwhile, on the last wavefront: Levinson-Durbin for the frame's LPC (it needs nothing from the
+        // pitch decisions) into a scratch vector, adopted below if analysis marks exist ...
+        const bool z = levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
+        if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
+        if ((g.C & 63) == 0) {
+            // ... and the impulse response of the new 1/A(z) for the block-form IIR (cum[] is dead after
+            // the normalisation; layout as in pitch_iir_wave)
+            lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
+            const int lane = tid & 63;
+            hpad[lane] = 0.0;
+            xp[lane] = (lane == 0) ? 1.0 : 0.0;
+            iir_fast_wave(xp, hpad + WAVE, WAVE, (const lds_f64 *)L.aPrev, g.orderPitch, (const lds_f64 *)nullptr, 1.0);
+        }
     }
     __syncthreads();
     STAMP(d, 4);
