@@ -433,3 +433,20 @@ def test_iir_mode_can_change_mid_frame():
         got[:, :, b * N:(b + 1) * N] = p.process(np.ascontiguousarray(x[:, :, b * N:(b + 1) * N]))
     err = got.astype(np.float64) - ref
     assert np.abs(err).max() <= 4e-7 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_register_light_kernel_variant_for_large_batches():
+    """Above 256 streams the host launches vp_k_pitch_lite (two workgroups per CU).  Same bar: bit-exact in
+    the default mode, and independent of which variant processed a stream."""
+    S, N, B = 320, 1024, 6
+    x = _streams(S, N * B)
+    got, _ = _gpu_run(x, N, {})                               # lite variant, exact IIR (lpcPitch 15 <= 16)
+    pick = [0, 5, 128, 255, 256, 319]
+    ref = _oracle_run(x[pick], N, {})
+    _assert_equal(got[pick], ref, "lite variant vs oracle")
+    small, _ = _gpu_run(np.ascontiguousarray(x[250:260]), N, {})      # regular variant
+    _assert_equal(small, got[250:260], "lite vs regular variant")
+    # lpcPitch 24 in exact mode must fall back to the regular kernel and stay exact
+    got24, _ = _gpu_run(x, N, dict(lpcPitch=24, vocBool=0))
+    ref24 = _oracle_run(x[[3, 300]], N, dict(lpcPitch=24, vocBool=0))
+    _assert_equal(got24[[3, 300]], ref24, "order 24, large batch")

@@ -336,13 +336,16 @@ __device__ __forceinline__ void iir_exact_generic(XP x, YP y, int n, AP aL, int 
 
 // Dispatch on the (wave-uniform) order.  hist as in iir_exact_lane; i0 = number of valid past
 // outputs before y[0] (only used by the generic path).
-template <class XP, class YP, class AP, class HP>
+// LITE = the register-light kernel variant (two workgroups per CU): only the small register-resident
+// instantiations, larger orders take the generic LDS form.
+template <bool LITE = false, class XP, class YP, class AP, class HP>
 __device__ __forceinline__ void iir_exact(XP x, YP y, int n, AP aL, int order_, HP hist, int i0, double gmul)
 {
     const int order = __builtin_amdgcn_readfirstlane(order_);
     const bool q = (__builtin_amdgcn_readfirstlane(n) & 3) == 0;
     if (q && order <= 8) iir_exact_lane<8>(x, y, n, aL, order, hist, gmul);
     else if (q && order <= 16) iir_exact_lane<16>(x, y, n, aL, order, hist, gmul);
+    else if (LITE) iir_exact_generic(x, y, n, aL, order, i0, gmul);
     else if (q && order <= 24) iir_exact_lane<24>(x, y, n, aL, order, hist, gmul);
     else if (q && order <= 32) iir_exact_lane<32>(x, y, n, aL, order, hist, gmul);
     else if (q && order <= 40) iir_exact_lane<40>(x, y, n, aL, order, hist, gmul);
@@ -1080,6 +1083,7 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
 
 // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
 // all 64 lanes run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
+template <bool LITE>
 __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &L, int nChunk, bool fast, bool &hValid)
 {
     if (fast && (g.C & 63) == 0 && g.orderPitch < WAVE) {
@@ -1104,13 +1108,14 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
         const int nh = min(order, shift);
         for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
         if (fast) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
-        else iir_exact(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
+        else iir_exact<LITE>(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
 }
 
+template <bool LITE>
 __device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool fast, bool &hValid)
 {
-    if (threadIdx.x < WAVE) pitch_iir_wave(g, L, nChunk, fast, hValid);
+    if (threadIdx.x < WAVE) pitch_iir_wave<LITE>(g, L, nChunk, fast, hValid);
     __syncthreads();
     STAMP(d, 8);
 }
@@ -1171,6 +1176,7 @@ __device__ __forceinline__ bool pitch_can_overlap(const VpGeom &g)
 // its residual and PSOLA done but not yet its IIR + output; wave 0 runs them here, next to the new
 // frame's YIN on the other waves (they touch disjoint data: the old frame's outEFrame/yFrame and
 // coefficients versus xs/yinTemp), and the new frame's buffers are zeroed only afterwards.
+template <bool LITE>
 __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
                                                      int pS, int s, int pendingCont, bool &hValid)
 {
@@ -1178,7 +1184,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     const int tid = threadIdx.x, nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
         if (pendingCont >= 0) {
-            if (tid < WAVE) { pitch_iir_wave(g, L, pendingCont, c.iirFast != 0, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+            if (tid < WAVE) { pitch_iir_wave<LITE>(g, L, pendingCont, c.iirFast != 0, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
         }
         __syncthreads();
         if (tid == 0) { st->nAn = 0; st->prevPitch = 0; st->gateOpen = 0; }
@@ -1197,7 +1203,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     {
         const int base = g.toKeep - g.tauMax;
         if (pendingCont >= 0 && (!pitch_can_overlap(g) || c.yinFft)) {      // no free wave: finish the old frame first
-            if (tid < WAVE) { pitch_iir_wave(g, L, pendingCont, c.iirFast != 0, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+            if (tid < WAVE) { pitch_iir_wave<LITE>(g, L, pendingCont, c.iirFast != 0, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
             __syncthreads();
             pendingCont = -1;
         }
@@ -1270,7 +1276,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             // waves 1..wavesY when that leaves wave 0 free for the previous frame's pending chunk
             const int yw0 = (wavesY <= 6) ? 1 : 0;
             if (yw0 == 1 && pendingCont >= 0 && tid < WAVE) {
-                pitch_iir_wave(g, L, pendingCont, c.iirFast != 0, hValid);
+                pitch_iir_wave<LITE>(g, L, pendingCont, c.iirFast != 0, hValid);
                 pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s);
             }
 #ifdef VP_DIAG_NO_YIN
@@ -1492,9 +1498,10 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     return 1;
 }
 
-__global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
+template <bool LITE>
+__device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in,
+                                                  float *__restrict__ out, double *smem)
 {
-    extern __shared__ double smem[];
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     PitchLds L;
@@ -1581,13 +1588,13 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre(g, c, d, L, pS, s, pendingCont, hValid);
+                mode = pitch_chunk_start_pre<LITE>(g, c, d, L, pS, s, pendingCont, hValid);
                 hValid = (mode != 0) && (g.C & 63) == 0 && g.orderPitch < WAVE;    // computed there for the new coefficients
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
             if (mode == 2) {
                 psola(g, d, L, nC, pS, qValid);
-                pitch_iir(g, d, L, nC, c.iirFast != 0, hValid);
+                pitch_iir<LITE>(g, d, L, nC, c.iirFast != 0, hValid);
             }
             if (mode >= 1) pitch_fill_output(g, c, d, L, nC, pS, s);
             __syncthreads();
@@ -1615,6 +1622,22 @@ __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, c
         __syncthreads();
         emit_block(g, c, d, out);
     }
+}
+
+__global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false>(g, c, d, in, out, smem);
+}
+
+// Register-light build of the same kernel (<= 128 VGPRs: two 512-thread workgroups per CU), selected by the
+// host for large batches when the exact IIR needs no big register-resident instantiation (FAST mode, or
+// lpcPitch <= 16).  With S >> 256 streams a second resident workgroup fills the first one's serial phases.
+__global__ __launch_bounds__(512, 4) void vp_k_pitch_lite(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                           float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<true>(g, c, d, in, out, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
