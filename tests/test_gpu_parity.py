@@ -450,3 +450,41 @@ def test_register_light_kernel_variant_for_large_batches():
     got24, _ = _gpu_run(x, N, dict(lpcPitch=24, vocBool=0))
     ref24 = _oracle_run(x[[3, 300]], N, dict(lpcPitch=24, vocBool=0))
     _assert_equal(got24[[3, 300]], ref24, "order 24, large batch")
+
+
+# ---- randomised sweep over sample rates, block sizes, orders, keys, gains and modes ---------------------------------------
+
+def _fuzz_case(seed):
+    rng = np.random.default_rng(seed)
+    fs = float(rng.choice([22050.0, 32000.0, 44100.0, 48000.0, 44099.0, 88200.0]))
+    N = int(rng.choice([64, 100, 278, 441, 512, 1000, 1024, 1536, 3000]))
+    params = dict(lpcVoice=int(rng.integers(2, 101)), lpcPitch=int(rng.integers(2, 101)), lpcSynth=int(rng.integers(2, 31)),
+                  keyPitch=int(rng.integers(0, 13)), gainPitch=float(rng.uniform(-20, 6)), gainVoc=float(rng.uniform(-20, 6)),
+                  gainVoice=float(rng.choice([-60.0, -30.0, 0.0])), gainSynth=float(rng.choice([-60.0, -12.0])),
+                  pitchBool=int(rng.random() < 0.85), vocBool=int(rng.random() < 0.7))
+    return fs, N, params
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_randomised_configurations_bit_exact(seed):
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    fs, N, params = _fuzz_case(1000 + seed)
+    S = 3
+    T = max(6, int(26000 * fs / 44100.0) // N) * N
+    x = _streams(S, T, fs=fs)
+    if seed % 3 == 0:
+        x[0, 0] *= np.where((np.arange(T) // 7000) % 2 == 0, 1.0, 2e-5).astype(np.float32)      # gate crossings
+    p = BatchVocoderProcessor(**params)
+    try:
+        p.prepareToPlay(fs, N, S)
+    except VpError as e:
+        assert e.code == -4, e                     # frame does not fit LDS at this sample rate: reported, not silent
+        pytest.skip(f"geometry for fs={fs} exceeds the LDS budget (VP_ERR_GEOMETRY)")
+    got = p.run(x)
+    ref = []
+    for s in range(S):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(fs, N)
+        ref.append(o.run(x[s]))
+    _assert_equal(got, np.stack(ref), f"seed {seed}: fs={fs} N={N} {params}")
