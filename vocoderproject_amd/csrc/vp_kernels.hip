@@ -1268,7 +1268,10 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             // x[i], so each element costs one new LDS value for two lags, the two accumulation chains
             // interleave, and with the window base made even (see xsAll) every read is an aligned
             // ds_read_b128.  (The one-lag-per-lane form below spent twice the LDS cycles, on
-            // ds_read2_b64 at half the LDS rate, and was LDS-bound at 30 us per frame.)
+            // ds_read2_b64 at half the LDS rate, and was LDS-bound at 30 us per frame.)  The eight
+            // elements of a trip are done as 16 differences, 16 squares, 16 ordered adds: left to
+            // the compiler each square and add directly followed its producer and paid the
+            // dependent-issue stall (17 ns per element instead of 14).
             typedef double d2 __attribute__((ext_vector_type(2)));
             typedef __attribute__((address_space(3))) d2 lds_d2;
             const int nPairs = (g.tauMax + 1) >> 1;
@@ -1293,7 +1296,13 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 #define VP_Y2LOAD(A, V, I) _Pragma("unroll") for (int u = 0; u < 4; u++) { A[u] = *(const lds_d2 *)(xa + (I) + 2 * u); V[u] = *(const lds_d2 *)(xw + (I) + 2 + 2 * u); }
 #define VP_Y2COMP(A, V) { const double e_[8] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y, A[3].x, A[3].y}; \
         const double w_[10] = {w0, w1, V[0].x, V[0].y, V[1].x, V[1].y, V[2].x, V[2].y, V[3].x, V[3].y}; \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) { double dA = e_[u] - w_[u], dB = e_[u] - w_[u + 1]; accA += dA * dA; accB += dB * dB; } \
+        double dA_[8], dB_[8]; \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { dA_[u] = e_[u] - w_[u]; dB_[u] = e_[u] - w_[u + 1]; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { dA_[u] = dA_[u] * dA_[u]; dB_[u] = dB_[u] * dB_[u]; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { accA += dA_[u]; accB += dB_[u]; } \
+        __builtin_amdgcn_sched_barrier(0); \
         w0 = w_[8]; w1 = w_[9]; }
                 if (F8 > 0) { VP_Y2LOAD(a0, v0, 0) }
                 for (int i = 0; i < F8; i += 16) {
