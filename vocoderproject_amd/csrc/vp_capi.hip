@@ -334,7 +334,10 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     h->vocLds = vp_voc_lds_bytes(W, nw);
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_fast, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_lite, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_lite_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_vocoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vocLds));
 
     VpDev d;
@@ -471,11 +474,9 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             // large batches: the register-light build lets two workgroups share a CU (needs <= 80 KB LDS each and
             // no big register-resident exact-IIR instantiation)
             const bool lite = g.S > 256 && !cp.yinFft && (cp.iirFast || g.orderPitch <= 16) && h->pitchLds <= 80 * 1024;
-            if (lite)
-                hipLaunchKernelGGL(vp_k_pitch_lite, dim3(g.S), dim3(512), h->pitchLds, st, g, cp, h->d, d_in, d_out);
-            else
-                hipLaunchKernelGGL(vp_k_pitch, dim3(g.S), dim3(512), h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0), st, g, cp,
-                                   h->d, d_in, d_out);
+            const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
+            auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
+            hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);
         }
     }
     hipError_t e = hipGetLastError();

@@ -29,8 +29,16 @@ typedef __attribute__((address_space(3))) int lds_i32;
 __device__ unsigned long long vp_last_stamp;
 #define STAMP(D, ID) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long _t = wall_clock64(); \
         (D).dbg[ID] += _t - vp_last_stamp; vp_last_stamp = _t; } } while (0)
-#define STAMP0(D) do { if (blockIdx.x == 0 && threadIdx.x == 0) vp_last_stamp = wall_clock64(); } while (0)
+#define STAMP0(D) do { if (blockIdx.x == 0 && threadIdx.x == 0) { vp_last_stamp = wall_clock64(); vp_dbg_g = (D).dbg; } } while (0)
+// inside helpers that do not see VpDev: ticks since the previous STAMPG_BEGIN/STAMPG, into dbg[ID]
+__device__ unsigned long long *vp_dbg_g;
+__device__ unsigned long long vp_last_g;
+#define STAMPG_BEGIN() do { if (blockIdx.x == 0 && threadIdx.x == 0) vp_last_g = wall_clock64(); } while (0)
+#define STAMPG(ID) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long _t = wall_clock64(); \
+        vp_dbg_g[ID] += _t - vp_last_g; vp_last_g = _t; } } while (0)
 #else
+#define STAMPG_BEGIN() do { } while (0)
+#define STAMPG(ID) do { } while (0)
 #define STAMP(D, ID) do { } while (0)
 #define STAMP0(D) do { } while (0)
 #endif
@@ -430,6 +438,7 @@ __device__ __forceinline__ void iir_block_wave(XP x, YP y, int n, AP aL, int ord
     const int lane = threadIdx.x & 63;
     const int order = __builtin_amdgcn_readfirstlane(order_);
     for (int b = 0; b < n; b += WAVE) {
+        STAMPG_BEGIN();
         // u_lane = -sum_{k=1..order} a[lane+k] * y[b-k]   (a beyond the order = 0; y before the start = 0):
         // the history values are wave-uniform reads, the trip count is uniform, two accumulators
         const int kmax = (b == 0) ? min(order, nh0) : order;
@@ -445,6 +454,7 @@ __device__ __forceinline__ void iir_block_wave(XP x, YP y, int n, AP aL, int ord
         if (k <= kmax) { const double a1 = (lane + k <= order) ? aL[lane + k] : 0.0; u0 = __builtin_fma(-a1, y[b - k], u0); }
         const double u = u0 + u1;
         xp[lane] = __builtin_fma(gmul, x[b + lane], u);
+        STAMPG(24);
         // 64-term dot product with four independent accumulators, eight terms read ahead per trip
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         const lds_f64 *hh = hpad + WAVE + lane;                             // hh[-j] = h[lane - j] (0 for j > lane)
@@ -466,8 +476,65 @@ __device__ __forceinline__ void iir_block_wave(XP x, YP y, int n, AP aL, int ord
         }
         const double acc = (acc0 + acc1) + (acc2 + acc3);
         y[b + lane] = acc;
+        STAMPG(25);
     }
 }
+
+// The same block form with the dot product kept off the LDS (orders <= 16, whole 64-sample blocks,
+// called by ONE full wavefront).  A DS instruction costs its wave 4-8 ns of issue even when nothing
+// waits for it (tools/ubench_lds.hip), and the LDS form above spends two of them per term.  Here
+//   * the lane's 64 taps H[j] = h[lane - j] stay in registers for the whole chunk (128 VGPRs),
+//   * the block's input is held as four registers X_q[lane] = x[b + 16 q + (lane & 15)] (every
+//     16-lane row holds the same 16 samples), so that term i = 16 q + m is ONE instruction,
+//     v_fmac_f64_dpp acc, X_q row_newbcast:m, H[i], with no broadcast traffic at all,
+//   * the carry-in of the previous block only reaches samples 0..order-1 <= 15, i.e. X_0: each row
+//     computes it for its own copy, and the 48 terms of X_1..X_3 are issued while the history
+//     values (the previous block's last outputs, written a moment ago) come back from the LDS.
+// Rounding differs from the LDS form only in the order of the partial sums (both are FAST mode).
+#define VP_BI_T(ACC, XQ, HI, M) \
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #M " row_mask:0xf bank_mask:0xf" : "+v"(ACC) : "v"(XQ), "v"(HI))
+#define VP_BI_ROW(XQ, Q) \
+    VP_BI_T(acc0, XQ, H[16 * Q + 0], 0);   VP_BI_T(acc1, XQ, H[16 * Q + 1], 1);   VP_BI_T(acc2, XQ, H[16 * Q + 2], 2);   \
+    VP_BI_T(acc3, XQ, H[16 * Q + 3], 3);   VP_BI_T(acc0, XQ, H[16 * Q + 4], 4);   VP_BI_T(acc1, XQ, H[16 * Q + 5], 5);   \
+    VP_BI_T(acc2, XQ, H[16 * Q + 6], 6);   VP_BI_T(acc3, XQ, H[16 * Q + 7], 7);   VP_BI_T(acc0, XQ, H[16 * Q + 8], 8);   \
+    VP_BI_T(acc1, XQ, H[16 * Q + 9], 9);   VP_BI_T(acc2, XQ, H[16 * Q + 10], 10); VP_BI_T(acc3, XQ, H[16 * Q + 11], 11); \
+    VP_BI_T(acc0, XQ, H[16 * Q + 12], 12); VP_BI_T(acc1, XQ, H[16 * Q + 13], 13); VP_BI_T(acc2, XQ, H[16 * Q + 14], 14); \
+    VP_BI_T(acc3, XQ, H[16 * Q + 15], 15);
+__device__ __forceinline__ void iir_block_wave_regs(const lds_f64 *x, lds_f64 *y, int n, const lds_f64 *aL, int order_,
+                                                    bool haveHist0, const lds_f64 *hpad)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+    double H[64], A[16];
+#pragma unroll
+    for (int j = 0; j < 64; j++) H[j] = hpad[WAVE + lane - j];                // h[lane - j], 0 for j > lane
+#pragma unroll
+    for (int k = 1; k <= 16; k++) A[k - 1] = (m + k <= order) ? -aL[m + k] : 0.0;  // -a[m + k]
+    double X1 = x[16 + m], X2 = x[32 + m], X3 = x[48 + m], X0 = x[m];
+    for (int b = 0; b < n; b += WAVE) {
+        // history: Y3[lane] = y[b - 16 + (lane & 15)] (zero before the frame's first sample), so that
+        // y[b - k] is lane 16 - k of the row
+        const bool hist = (b > 0) || haveHist0;
+        double Y3 = 0.0;
+        if (hist) Y3 = y[b - 16 + m];
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        VP_BI_ROW(X1, 1)
+        VP_BI_ROW(X2, 2)
+        VP_BI_ROW(X3, 3)
+        double u0 = 0.0, u1 = 0.0;
+        VP_BI_T(u0, Y3, A[0], 15);  VP_BI_T(u1, Y3, A[1], 14);  VP_BI_T(u0, Y3, A[2], 13);  VP_BI_T(u1, Y3, A[3], 12);
+        VP_BI_T(u0, Y3, A[4], 11);  VP_BI_T(u1, Y3, A[5], 10);  VP_BI_T(u0, Y3, A[6], 9);   VP_BI_T(u1, Y3, A[7], 8);
+        VP_BI_T(u0, Y3, A[8], 7);   VP_BI_T(u1, Y3, A[9], 6);   VP_BI_T(u0, Y3, A[10], 5);  VP_BI_T(u1, Y3, A[11], 4);
+        VP_BI_T(u0, Y3, A[12], 3);  VP_BI_T(u1, Y3, A[13], 2);  VP_BI_T(u0, Y3, A[14], 1);  VP_BI_T(u1, Y3, A[15], 0);
+        X0 = X0 + (u0 + u1);
+        asm volatile("s_nop 1" : "+v"(X0));                                   // VALU write of X0 -> DPP read: 2 wait states
+        VP_BI_ROW(X0, 0)
+        y[b + lane] = (acc0 + acc1) + (acc2 + acc3);
+        const int bn = b + WAVE;
+        if (bn < n) { X0 = x[bn + m]; X1 = x[bn + 16 + m]; X2 = x[bn + 32 + m]; X3 = x[bn + 48 + m]; }
+    }
+}
+#undef VP_BI_ROW
 
 // ------------------------------------------------------------------------------------------------
 // K1: vocoder.  VocoderProcess::process/processWindow (VocoderProcess.cpp:173-223), one workgroup
@@ -1083,10 +1150,10 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
 
 // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
 // all 64 lanes run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
-template <bool LITE>
-__device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &L, int nChunk, bool fast, bool &hValid)
+template <bool LITE, bool FAST>
+__device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &L, int nChunk, bool &hValid)
 {
-    if (fast && (g.C & 63) == 0 && g.orderPitch < WAVE) {
+    if (FAST && (g.C & 63) == 0 && g.orderPitch < WAVE) {
         // block form; the impulse response of the frame's 1/A(z) lives in cum[128..256) (64 zeros in front)
         const int shift = nChunk * g.C, order = g.orderPitch;
         lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
@@ -1097,7 +1164,10 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
             iir_fast_wave(xp, hpad + WAVE, WAVE, (const lds_f64 *)L.st->a, order, (const lds_f64 *)nullptr, 1.0);
             hValid = true;
         }
-        iir_block_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, xp, 1.0);
+        if (!LITE && order <= 16)
+            iir_block_wave_regs((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, shift > 0, hpad);
+        else
+            iir_block_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, xp, 1.0);
         return;
     }
     {
@@ -1107,15 +1177,15 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
         lds_f64 *hist = L.cum;                          // yinTemp scratch is free here
         const int nh = min(order, shift);
         for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
-        if (fast) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
+        if (FAST) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
         else iir_exact<LITE>(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
 }
 
-template <bool LITE>
-__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool fast, bool &hValid)
+template <bool LITE, bool FAST>
+__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool &hValid)
 {
-    if (threadIdx.x < WAVE) pitch_iir_wave<LITE>(g, L, nChunk, fast, hValid);
+    if (threadIdx.x < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
     __syncthreads();
     STAMP(d, 8);
 }
@@ -1176,7 +1246,7 @@ __device__ __forceinline__ bool pitch_can_overlap(const VpGeom &g)
 // its residual and PSOLA done but not yet its IIR + output; wave 0 runs them here, next to the new
 // frame's YIN on the other waves (they touch disjoint data: the old frame's outEFrame/yFrame and
 // coefficients versus xs/yinTemp), and the new frame's buffers are zeroed only afterwards.
-template <bool LITE>
+template <bool LITE, bool FAST>
 __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
                                                      int pS, int s, int pendingCont, bool &hValid)
 {
@@ -1184,7 +1254,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     const int tid = threadIdx.x, nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
         if (pendingCont >= 0) {
-            if (tid < WAVE) { pitch_iir_wave<LITE>(g, L, pendingCont, c.iirFast != 0, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+            if (tid < WAVE) { pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
         }
         __syncthreads();
         if (tid == 0) { st->nAn = 0; st->prevPitch = 0; st->gateOpen = 0; }
@@ -1203,7 +1273,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     {
         const int base = g.toKeep - g.tauMax;
         if (pendingCont >= 0 && (!pitch_can_overlap(g) || c.yinFft)) {      // no free wave: finish the old frame first
-            if (tid < WAVE) { pitch_iir_wave<LITE>(g, L, pendingCont, c.iirFast != 0, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+            if (tid < WAVE) { pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
             __syncthreads();
             pendingCont = -1;
         }
@@ -1279,7 +1349,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             // waves 1..wavesY when that leaves wave 0 free for the previous frame's pending chunk
             const int yw0 = (wavesY <= 6) ? 1 : 0;
             if (yw0 == 1 && pendingCont >= 0 && tid < WAVE) {
-                pitch_iir_wave<LITE>(g, L, pendingCont, c.iirFast != 0, hValid);
+                pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid);
                 pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s);
             }
 #ifdef VP_DIAG_NO_YIN
@@ -1507,7 +1577,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     return 1;
 }
 
-template <bool LITE>
+template <bool LITE, bool FAST>
 __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in,
                                                   float *__restrict__ out, double *smem)
 {
@@ -1597,13 +1667,13 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre<LITE>(g, c, d, L, pS, s, pendingCont, hValid);
+                mode = pitch_chunk_start_pre<LITE, FAST>(g, c, d, L, pS, s, pendingCont, hValid);
                 hValid = (mode != 0) && (g.C & 63) == 0 && g.orderPitch < WAVE;    // computed there for the new coefficients
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
             if (mode == 2) {
                 psola(g, d, L, nC, pS, qValid);
-                pitch_iir<LITE>(g, d, L, nC, c.iirFast != 0, hValid);
+                pitch_iir<LITE, FAST>(g, d, L, nC, hValid);
             }
             if (mode >= 1) pitch_fill_output(g, c, d, L, nC, pS, s);
             __syncthreads();
@@ -1633,10 +1703,21 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     }
 }
 
+// Four builds of the one body: the IIR mode is a compile-time choice so that the exact recursion's big
+// register-resident instantiations and the block form's 64 resident taps never meet in one register
+// allocation (together they pushed kernel-invariant values into scratch, and every reload in a serial
+// phase is a memory round trip), and each build carries half the code.
 __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false>(g, c, d, in, out, smem);
+}
+
+__global__ __launch_bounds__(512) void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                       float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, true>(g, c, d, in, out, smem);
 }
 
 // Register-light build of the same kernel (<= 128 VGPRs: two 512-thread workgroups per CU), selected by the
@@ -1646,7 +1727,14 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite(VpGeom g, VpCall c, Vp
                                                            float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, false>(g, c, d, in, out, smem);
+}
+
+__global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                                float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<true, true>(g, c, d, in, out, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
