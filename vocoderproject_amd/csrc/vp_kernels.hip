@@ -795,7 +795,7 @@ __device__ __forceinline__ int bitrev(int k, int logM) { return (int)(__brev((un
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
 typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
-    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *fft;
+    lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *htab, *fft;
     lds_state *st;
     lds_minidx *part;  // [8]
     int *ishare;       // [4] (generic pointer: used with atomicMin)
@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
     const int tid = threadIdx.x, nt = blockDim.x;
     const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
     const int nG = 2 * T + 1;
-    const double *hw = d.hannTab + d.hannOff[T];
+    const lds_f64 *hw = L.htab;                       // d.hannTab + d.hannOff[T], staged below
     const double beta = st->beta;
     const int nSt = st->nSt;
     GrainTab G;
@@ -1060,11 +1060,12 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
     G.startIdx = G.flags + VP_MARKS; G.stopIdx = G.startIdx + VP_MARKS;
     // xInterp[j] - stMark = (j - T)/beta is the same for every grain of the frame (:700,715,731):
     // the 2T+1 quotients are computed once per frame, x[j] is then one exact add away.
-    if (!qValid) {
-        for (int j = tid; j < nG; j += nt) L.qtab[j] = (double)(j - T) / beta;
+    if (!qValid) {                                    // once per frame and kernel launch; later chunks come here behind a barrier
+        const double *hg = d.hannTab + d.hannOff[T];
+        for (int j = tid; j < nG; j += nt) { L.qtab[j] = (double)(j - T) / beta; L.htab[j] = hg[j]; }
         qValid = true;
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < WAVE) {
         // one lane per synthesis mark: the marks ascend, so the marks that are due in this chunk
         // (:685 stMark - T < (nChunk+1) C) form a prefix of the pending ones; each lane prepares
@@ -1597,7 +1598,8 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     L.aPrev = L.r + (VP_ORDER_MAX + 1);
     L.qtab = L.aPrev + (VP_ORDER_MAX + 1);            // [2 tauMax + 2] PSOLA quotient table (also Levinson scratch)
     L.qtab += (int)((L.qtab - (lds_f64 *)smem) & 1);  // keep it 16-byte aligned
-    L.part = (lds_minidx *)(L.qtab + (2 * g.tauMax + 2));
+    L.htab = L.qtab + (2 * g.tauMax + 2);             // [2 tauMax + 2] the frame's Hann(2T+1) window, staged from the global table
+    L.part = (lds_minidx *)(L.htab + (2 * g.tauMax + 2));
     L.st = (lds_state *)(L.part + 8);
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
     L.fft = (lds_f64 *)(L.st + 1) + 8;                // [2 << fftLog] only when launched with the FFT extension
