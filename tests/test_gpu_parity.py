@@ -488,3 +488,21 @@ def test_randomised_configurations_bit_exact(seed):
         o.prepare_to_play(fs, N)
         ref.append(o.run(x[s]))
     _assert_equal(got, np.stack(ref), f"seed {seed}: fs={fs} N={N} {params}")
+
+
+def test_pitch_kernel_build_selection():
+    """The four builds of the pitch kernel (IIR mode x register budget) are selected as documented."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    p = BatchVocoderProcessor(vocBool=0)
+    assert p.pitch_kernel_name() == ""
+    p.prepareToPlay(FS, 1024, 8)
+    assert p.pitch_kernel_name() == "vp_k_pitch"
+    p.set_iir_mode("fast")
+    assert p.pitch_kernel_name() == "vp_k_pitch_fast"
+    q = BatchVocoderProcessor(vocBool=0)
+    q.prepareToPlay(FS, 1024, 300)
+    assert q.pitch_kernel_name() == "vp_k_pitch_lite"
+    q.set_iir_mode("fast")
+    assert q.pitch_kernel_name() == "vp_k_pitch_lite_fast"
+    q.set_yin_mode("fft")
+    assert q.pitch_kernel_name() == "vp_k_pitch_fast"            # the FFT accelerator needs the full build's LDS

@@ -16,6 +16,7 @@ PHASES = {0: "pitch: load xs", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/n
           4: "pitch: st marks", 5: "pitch: levinson", 6: "pitch: FIR start", 7: "pitch: psola", 8: "pitch: IIR",
           9: "pitch: fill output", 12: "pitch:   (cum sum)", 13: "pitch:   (normalise)", 14: "pitch:   (psola qtab+grain table)", 10: "pitch: FIR cont", 11: "pitch: state out",
           24: "pitch:   (block IIR carry-in, all chunks)", 25: "pitch:   (block IIR 64-term dot, all chunks)",
+          26: "pitch:   (last wave: LPC autocorrelation)", 27: "pitch:   (last wave: Levinson-Durbin)",
           16: "voc: load", 17: "voc: autocorr", 18: "voc: levinson", 19: "voc: FIR", 20: "voc: energies",
           21: "voc: gains", 22: "voc: IIR", 23: "voc: scale+OLA"}
 

@@ -71,6 +71,20 @@ extern "C" const char *vp_error_string(int code)
 
 extern "C" const char *vp_last_error(const vp_handle *h) { return h ? h->lastError.c_str() : ""; }
 
+// large batches: the register-light build lets two workgroups share a CU (needs <= 80 KB LDS each and no big
+// register-resident exact-IIR instantiation)
+static bool pitch_lite(const vp_handle *h, bool iirFast, bool yinFft)
+{
+    return h->g.S > 256 && !yinFft && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024;
+}
+
+extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
+{
+    if (!h || !h->prepared) return "";
+    const bool fast = h->iirMode == VP_IIR_FAST, lite = pitch_lite(h, fast, h->yinMode == VP_YIN_FFT);
+    return lite ? (fast ? "vp_k_pitch_lite_fast" : "vp_k_pitch_lite") : (fast ? "vp_k_pitch_fast" : "vp_k_pitch");
+}
+
 extern "C" const char *vp_kernel_slot_name(int slot)
 {
     static const char *n[VP_NUM_KERNEL_SLOTS] = {"vp_k_ingest_gate", "vp_k_vocoder", "vp_k_pitch", "vp_k_emit"};
@@ -473,7 +487,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             ProfScope ps(h, st, 2);
             // large batches: the register-light build lets two workgroups share a CU (needs <= 80 KB LDS each and
             // no big register-resident exact-IIR instantiation)
-            const bool lite = g.S > 256 && !cp.yinFft && (cp.iirFast || g.orderPitch <= 16) && h->pitchLds <= 80 * 1024;
+            const bool lite = pitch_lite(h, cp.iirFast != 0, cp.yinFft != 0);
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
             hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);

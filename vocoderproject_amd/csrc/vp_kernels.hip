@@ -36,7 +36,14 @@ __device__ unsigned long long vp_last_g;
 #define STAMPG_BEGIN() do { if (blockIdx.x == 0 && threadIdx.x == 0) vp_last_g = wall_clock64(); } while (0)
 #define STAMPG(ID) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long _t = wall_clock64(); \
         vp_dbg_g[ID] += _t - vp_last_g; vp_last_g = _t; } } while (0)
+// the same for the LAST thread of workgroup 0 (work parked on the last wavefront)
+__device__ unsigned long long vp_last_l;
+#define STAMPL_BEGIN() do { if (blockIdx.x == 0 && threadIdx.x == blockDim.x - 1) vp_last_l = wall_clock64(); } while (0)
+#define STAMPL(ID) do { if (blockIdx.x == 0 && threadIdx.x == blockDim.x - 1) { unsigned long long _t = wall_clock64(); \
+        vp_dbg_g[ID] += _t - vp_last_l; vp_last_l = _t; } } while (0)
 #else
+#define STAMPL_BEGIN() do { } while (0)
+#define STAMPL(ID) do { } while (0)
 #define STAMPG_BEGIN() do { } while (0)
 #define STAMPG(ID) do { } while (0)
 #define STAMP(D, ID) do { } while (0)
@@ -45,6 +52,17 @@ __device__ unsigned long long vp_last_g;
 
 // ------------------------------------------------------------------------------------------------
 // helpers
+
+// threadIdx.x through an opaque move.  Index arithmetic derived from the plain builtin is loop-invariant
+// for the whole kernel; the compiler hoists it all to the top and then has to spill it around the
+// register-heavy phases (every reload in a serial phase is a memory round trip).  Derived from this
+// value it is recomputed where it is used.
+__device__ __forceinline__ int vp_tid()
+{
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out);
 
@@ -230,6 +248,85 @@ __device__ __forceinline__ bool levinson_wave(RP r, AP a, int order, int aLen, d
     a1 *= -1.;
     if (lane <= order) a[lane] = a0;
     if (64 + lane <= order) a[64 + lane] = a1;
+    return false;
+}
+
+// RUN += (lane U of V's 16-lane row) * ONE in one VALU op (DPP row broadcast; ONE must hold 1.0, so the
+// fused multiply-add rounds exactly like RUN + value).
+#define VP_FMAC_BCAST(RUN, V, ONE, U) \
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #U " row_mask:0xf bank_mask:0xf" : "+v"(RUN) : "v"(V), "v"(ONE))
+
+// A stretch [n0, n1) of the LPC autocorrelation sum_n x[n] x[n+m] (LPC.cpp:44-97), continued from `sum`,
+// by one full wavefront with lane -> lag m.  n0 and n1 are multiples of 8 and n1 <= F - (largest lag).
+// Eight elements per trip, the next trip's LDS reads issued before this trip's arithmetic; product and
+// sum stay two roundings, in the reference's order.  (v_mul_f64 has no DPP form on gfx950 -- only
+// v_fmac_f64 does -- so the wave-uniform factor x[n] is an LDS broadcast read.)
+__device__ __forceinline__ double autocorr_stretch(const lds_f64 *x, int m, int n0, int n1, double sum)
+{
+    const lds_f64 *xm = x + m;
+    if (n0 >= n1) return sum;
+    double a0[8], b0[8], a1[8], b1[8];
+#define VP_ALOAD(A, B, I) _Pragma("unroll") for (int u = 0; u < 8; u++) { A[u] = x[(I) + u]; B[u] = xm[(I) + u]; }
+#define VP_ACOMP(A, B) { double p_[8]; _Pragma("unroll") for (int u = 0; u < 8; u++) p_[u] = A[u] * B[u]; \
+                         __builtin_amdgcn_sched_barrier(0); \
+                         _Pragma("unroll") for (int u = 0; u < 8; u++) sum += p_[u]; \
+                         __builtin_amdgcn_sched_barrier(0); }
+    VP_ALOAD(a0, b0, n0)
+    for (int n = n0; n < n1; n += 16) {
+        const bool more1 = n + 8 < n1;
+        if (more1) { VP_ALOAD(a1, b1, n + 8) }
+        VP_ACOMP(a0, b0)
+        if (more1) {
+            if (n + 16 < n1) { VP_ALOAD(a0, b0, n + 16) }
+            VP_ACOMP(a1, b1)
+        }
+    }
+#undef VP_ALOAD
+#undef VP_ACOMP
+    return sum;
+}
+
+// Levinson-Durbin for orders below 16 with the coefficient vector inside ONE 16-lane row (lane m of
+// every row owns a[m]; the four rows of the calling wavefront work redundantly).  The ordered sums
+// rho_a = sum_{i=1..p-1} r[p-i] a[i] and r_a = sum r[i] a[i] (LPC.cpp:120-128) are chains of
+// v_fmac_f64 with a DPP row-broadcast operand: entries i >= p hold +0.0, and adding +0.0 to a sum that
+// started from +0.0 changes nothing, so all fifteen terms are always added and no lane ever talks to
+// the LDS for them (the general form's park-and-read-back costs two LDS round trips per order step).
+template <class RP, class AP>
+__device__ __forceinline__ bool levinson_row16(RP r, AP a, int order, int aLen, double eps)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    if (fabs(r[0]) < eps) {                        // :110-114
+        for (int i = lane; i < aLen; i += WAVE) a[i] = (i == 0) ? 1.0 : 0.0;
+        return true;
+    }
+    const double r0 = r[0], one = 1.0;
+    double av = 0.0;                                 // a[m]
+    if (m == 0) av = 1.0;
+    if (m == 1) av = r[1] / r0;
+    const double rl = (m >= 1 && m <= order) ? r[m] : 0.0;
+    double rq = (m >= 1 && m < 2) ? r[2 - m] : 0.0;  // r[p - m] of the coming step
+    for (int p = 2; p < order + 1; p++) {
+        const bool in = m >= 1 && m < p;
+        double q = in ? rq * av : 0.0;
+        double sv = rl * av;
+        const double rp = r[p];
+        const double partner = __shfl(av, (lane & 48) | ((p - m) & 15), WAVE);      // a[p - m]
+        if (p + 1 < order + 1) rq = (m >= 1 && m < p + 1) ? r[p + 1 - m] : 0.0;
+        double rho_a = 0.0, r_a = 0.0;
+        asm volatile("s_nop 1" : "+v"(q), "+v"(sv));                             // VALU write -> DPP read
+#define VP_LV(U) VP_FMAC_BCAST(rho_a, q, one, U); VP_FMAC_BCAST(r_a, sv, one, U);
+        VP_LV(1) VP_LV(2) VP_LV(3) VP_LV(4) VP_LV(5) VP_LV(6) VP_LV(7) VP_LV(8)
+        VP_LV(9) VP_LV(10) VP_LV(11) VP_LV(12) VP_LV(13) VP_LV(14) VP_LV(15)
+#undef VP_LV
+        const double k = (rp - rho_a) / (r0 - r_a);
+        double nv = av;
+        if (in) nv = av - k * partner;
+        if (m == p) nv = k;
+        av = nv;
+    }
+    if (m >= 1) av *= -1.;
+    if (lane <= order) a[lane] = av;
     return false;
 }
 
@@ -1048,7 +1145,7 @@ struct GrainTab {                       // lives in the yinTemp/cum scratch, fre
 __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS, bool &qValid)
 {
     lds_state *st = L.st;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = vp_tid(), nt = blockDim.x;
     const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
     const int nG = 2 * T + 1;
     const lds_f64 *hw = L.htab;                       // d.hannTab + d.hannOff[T], staged below
@@ -1186,7 +1283,7 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
 template <bool LITE, bool FAST>
 __device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool &hValid)
 {
-    if (threadIdx.x < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
+    if (vp_tid() < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
     __syncthreads();
     STAMP(d, 8);
 }
@@ -1196,7 +1293,7 @@ __device__ __forceinline__ void pitch_fill_output_wave(const VpGeom &g, const Vp
                                                        int nChunk, int pS, int s)
 {
     double *acc = d.outAcc + (size_t)s * g.outSize;
-    for (int i = threadIdx.x & 63; i < g.C; i += WAVE) {
+    for (int i = vp_tid() & 63; i < g.C; i += WAVE) {
         int pos = (c.outCounter + pS + i) % g.outSize;
         acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
     }
@@ -1207,7 +1304,7 @@ __device__ __forceinline__ void pitch_fill_output(const VpGeom &g, const VpCall 
 {
     // PitchProcess::fillOutputBuffer (PitchProcess.cpp:328-342)
     double *acc = d.outAcc + (size_t)s * g.outSize;
-    for (int i = threadIdx.x; i < g.C; i += blockDim.x) {
+    for (int i = vp_tid(); i < g.C; i += blockDim.x) {
         int pos = (c.outCounter + pS + i) % g.outSize;
         acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
     }
@@ -1224,7 +1321,7 @@ __device__ __forceinline__ bool pitch_chunk_cont_pre(const VpGeom &g, const VpCa
     if (L.st->nAn == 0) return false;
     const int order = g.orderPitch;
     const lds_f64 *a = L.st->a;
-    for (int i = threadIdx.x; i < g.C; i += blockDim.x) {                   // filterFIR(F-C, C, toKeep+F+(n-1)C)
+    for (int i = vp_tid(); i < g.C; i += blockDim.x) {                   // filterFIR(F-C, C, toKeep+F+(n-1)C)
         int xi = g.toKeep + g.F - g.C + i;
         double e = a[0] * L.xs[xi];
         for (int k = 1; k <= order; k++) e += L.xs[xi - k] * a[k];
@@ -1252,7 +1349,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
                                                      int pS, int s, int pendingCont, bool &hValid)
 {
     lds_state *st = L.st;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = vp_tid(), nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
         if (pendingCont >= 0) {
             if (tid < WAVE) { pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
@@ -1270,6 +1367,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         st->pitch = 0; st->period = 0;
         L.ishare[0] = INT_MAX;
     }
+    // LPC ahead of the pitch decisions (see below): needs the time-domain autocorrelation on one wavefront
+    const bool specLpc = !c.yinFft && g.orderPitch < WAVE && nt >= 8 * WAVE;
+    const int acM = min(nt - 1 - tid, g.orderPitch);                         // the last wavefront's lag per lane
+    const int acSplit = min((g.F * 15 / 16) & ~15, (g.F - g.orderPitch) & ~15);  // how much of the sum runs beside YIN
+    double acSum = 0.0;
     // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
     {
         const int base = g.toKeep - g.tauMax;
@@ -1449,6 +1551,14 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     {
         const int order = g.orderPitch;
         const lds_f64 *x = L.xs + g.toKeep;
+        STAMPL_BEGIN();
+        if (specLpc) {
+            // an order below 64 has all its lags on the LAST wavefront (lane -> lag, spare lanes redo lag
+            // `order`).  It shares its SIMD with a YIN wavefront, so only the first stretch of the sum is done
+            // here; the chain is carried in a register across the barrier and finished, followed by
+            // Levinson-Durbin, while wave 0 runs the cumulative sum below.
+            if (tid >= nt - WAVE) acSum = autocorr_stretch(x, acM, 0, acSplit, 0.0);
+        } else
 #ifdef VP_DIAG_NO_AUTOCORR
         if (false)
 #endif
@@ -1477,12 +1587,32 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             for (int n = c8; n < cnt; n++) sum += x[n] * xm[n];
             if (m0 <= order) L.r[m] = sum / (double)g.F;
         }
-
+        STAMPL(26);
     }
     __syncthreads();
-    for (int i = tid; i < g.eLen; i += nt) L.eF[i] = 0.0;                  // :216-218 (after the old frame's last chunk is out)
+    // :216-218 (after the old frame's last chunk is out).  With specLpc the residual of the whole frame is
+    // written straight into eFrame further down (every entry below toKeep + F), so only the tail is
+    // zeroed here; a frame without analysis marks zeroes the rest again.
+    for (int i = (specLpc ? g.toKeep + g.F : 0) + tid; i < g.eLen; i += nt) L.eF[i] = 0.0;
     for (int i = tid; i < g.F; i += nt) { L.oE[i] = 0.0; L.yF[i] = 0.0; }
     STAMP(d, 1);
+    if (specLpc && tid >= nt - WAVE) {
+        // the rest of the autocorrelation (uniform stretch, then the lag-dependent tail), then the LPC
+        // itself (it needs nothing from the pitch decisions) into a scratch vector that is adopted below
+        // if analysis marks exist
+        STAMPL_BEGIN();
+        const lds_f64 *x = L.xs + g.toKeep, *xm = x + acM;
+        const int nU = (g.F - g.orderPitch) & ~7;
+        acSum = autocorr_stretch(x, acM, acSplit, nU, acSum);
+        for (int n = nU; n < g.F - acM; n++) acSum += x[n] * xm[n];
+        L.r[acM] = acSum / (double)g.F;                                       // spare lanes: identical stores
+        STAMPL(26);
+        const int order = g.orderPitch;
+        const bool z = (order < 16) ? levinson_row16(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
+                                    : levinson_wave(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
+        if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
+        STAMPL(27);
+    }
     if (tid < WAVE) {                                                        // :395-402 running sum tmp += yinTemp[k], in order
         // every lane of wave 0 runs the same chain (full EXEC); eight entries per trip are read
         // ahead so that only the dependent adds remain on the critical path
@@ -1537,13 +1667,31 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         pitch_marks(g, L, d.ub);
         STAMP(d, 3);
         place_st_marks(g, c, d, st);
+    } else if (specLpc && tid < nt - WAVE) {
+        // meanwhile, on the middle wavefronts: filterFIR(-toKeep, toKeep+F, 0) :280-302 with the new
+        // coefficients (speculative: only used if analysis marks exist); the wavefront that shares wave 0's
+        // SIMD (wave 4) stays out of the serial code's way
+        const int wv = tid >> 6, nw = nt >> 6;
+        if (nw < 8 || wv != 4) {
+            const int rank = (nw < 8 || wv < 4) ? wv - 1 : wv - 2, nWork = (nw < 8) ? nw - 2 : nw - 3;
+            const int order = g.orderPitch;
+            const lds_f64 *a = L.aPrev;
+            for (int j = rank * WAVE + (tid & 63); j < g.toKeep + g.F; j += nWork * WAVE) {
+                double e = a[0] * L.xs[j];
+                int kmax = min(order, j);
+                for (int k = 1; k <= kmax; k++) e += L.xs[j - k] * a[k];
+                L.eF[j] = e;
+            }
+        }
     } else if (tid >= nt - WAVE && g.orderPitch < WAVE) {
-        // meanwhile, on the last wavefront: Levinson-Durbin for the frame's LPC (it needs nothing from the
-        // pitch decisions) into a scratch vector, adopted below if analysis marks exist ...
-        const bool z = levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
-        if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
+        // meanwhile, on the last wavefront (FFT mode: Levinson-Durbin first, the autocorrelation came late) ...
+        if (!specLpc) {
+            const bool z = (g.orderPitch < 16) ? levinson_row16(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps)
+                                               : levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);
+            if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
+        }
         if ((g.C & 63) == 0) {
-            // ... and the impulse response of the new 1/A(z) for the block-form IIR (cum[] is dead after
+            // ... the impulse response of the new 1/A(z) for the block-form IIR (cum[] is dead after
             // the normalisation; layout as in pitch_iir_wave)
             lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
             const int lane = tid & 63;
@@ -1560,6 +1708,12 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             for (int i = tid; i < ncopy; i += nt) st->a[i] = L.aPrev[i];
         } else if (tid < WAVE)
             levinson_wave(L.r, (lds_f64 *)st->a, g.orderPitch, VP_ORDER_MAX + 1, g.levEps);
+        if (specLpc) {                                                        // the residual is already in eFrame
+            if (tid == 0) st->stMarkIdx = 0;
+            __syncthreads();
+            STAMP(d, 5);
+            return 2;
+        }
         __syncthreads();
         STAMP(d, 5);
         const int order = g.orderPitch;
@@ -1574,6 +1728,9 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         __syncthreads();
         STAMP(d, 6);
         return 2;
+    }
+    if (specLpc) {                                                            // no analysis marks: the frame stays as :216-218 left it
+        for (int i = tid; i < g.toKeep + g.F; i += nt) L.eF[i] = 0.0;
     }
     return 1;
 }
@@ -1632,6 +1789,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     int pS = c.pStart, nChunk = c.nChunk0;
     bool qValid = false, hValid = hValid0;
     for (int step = 0; step < c.nSteps; step++) {
+        const int tid = vp_tid();
         // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double.  Consecutive steps
         // overlap by all but C samples, so the ring is read once per g.xsSteps steps (once per block
         // when LDS allows) and the step's window is just an offset into that span.
