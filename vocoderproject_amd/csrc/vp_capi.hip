@@ -324,10 +324,12 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     g.xsSteps = 1;
     {
         const int stepsMax = (N + g.C - 1) / g.C;
+        // batches that can use the two-workgroups-per-CU build keep the frame within half a CU's LDS
+        const size_t budget = std::min<size_t>(ldsMax, (g.S > 256 ? 80 : 112) * 1024);
         for (int k = stepsMax; k >= 1; k--) {
             VpGeom t = g;
             t.xsSteps = k;
-            if ((size_t)(g.toKeep + F + (k - 1) * g.C) < (size_t)g.inSize && vp_pitch_lds_bytes(t) <= std::min<size_t>(ldsMax, 112 * 1024)) { g.xsSteps = k; break; }
+            if ((size_t)(g.toKeep + F + (k - 1) * g.C) < (size_t)g.inSize && vp_pitch_lds_bytes(t) <= budget) { g.xsSteps = k; break; }
         }
     }
     h->pitchLds = vp_pitch_lds_bytes(g);
