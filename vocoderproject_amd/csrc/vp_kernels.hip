@@ -337,6 +337,27 @@ template <class EP>
 __device__ __forceinline__ void energy_pair_wave(EP e0, EP e1, int n, double &E0, double &E1)
 {
     double r0 = 0.0, r1 = 0.0;
+    if ((n & 15) == 0) {
+        // sixteen entries per trip: ONE read per array (lane l holds entry i + (l & 15), every 16-lane
+        // row the same), the squares computed once, lane-parallel, and the two ordered sums taken as
+        // chains of v_fmac_f64 with a DPP row-broadcast operand (x * 1.0 + run rounds like run + x).
+        // Per element this is two VALU ops and an eighth of an LDS read instead of two loads, two
+        // multiplies and two adds done redundantly by every lane.
+        const int l16 = threadIdx.x & 15;
+        const double one = 1.0;
+        double v0 = e0[l16], v1 = e1[l16];
+        for (int i = 0; i < n; i += 16) {
+            double s0 = v0 * v0, s1 = v1 * v1;
+            if (i + 16 < n) { v0 = e0[i + 16 + l16]; v1 = e1[i + 16 + l16]; }
+            asm volatile("s_nop 1" : "+v"(s0), "+v"(s1));                      // VALU write -> DPP read
+#define VP_EN(U) VP_FMAC_BCAST(r0, s0, one, U); VP_FMAC_BCAST(r1, s1, one, U);
+            VP_EN(0) VP_EN(1) VP_EN(2) VP_EN(3) VP_EN(4) VP_EN(5) VP_EN(6) VP_EN(7)
+            VP_EN(8) VP_EN(9) VP_EN(10) VP_EN(11) VP_EN(12) VP_EN(13) VP_EN(14) VP_EN(15)
+#undef VP_EN
+        }
+        E0 = r0; E1 = r1;
+        return;
+    }
     const int n8 = n & ~7;
     for (int i = 0; i < n8; i += 8) {
         double a[8], b[8];
