@@ -17,6 +17,9 @@ PHASES = {0: "pitch: load xs", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/n
           9: "pitch: fill output", 12: "pitch:   (cum sum)", 13: "pitch:   (normalise)", 14: "pitch:   (psola qtab+grain table)", 10: "pitch: FIR cont", 11: "pitch: state out",
           24: "pitch:   (block IIR carry-in, all chunks)", 25: "pitch:   (block IIR 64-term dot, all chunks)",
           26: "pitch:   (last wave: LPC autocorrelation)", 27: "pitch:   (last wave: Levinson-Durbin)",
+          40: "pitch:   (YIN phase, wave 0 busy)", 41: "pitch:   (YIN phase, wave 1 busy)", 42: "pitch:   (YIN phase, wave 2 busy)",
+          43: "pitch:   (YIN phase, wave 3 busy)", 44: "pitch:   (YIN phase, wave 4 busy)", 45: "pitch:   (YIN phase, wave 5 busy)",
+          46: "pitch:   (YIN phase, wave 6 busy)", 47: "pitch:   (YIN phase, wave 7 busy)",
           16: "voc: load", 17: "voc: autocorr", 18: "voc: levinson", 19: "voc: FIR", 20: "voc: energies",
           21: "voc: gains", 22: "voc: IIR", 23: "voc: scale+OLA"}
 

@@ -41,7 +41,14 @@ __device__ unsigned long long vp_last_l;
 #define STAMPL_BEGIN() do { if (blockIdx.x == 0 && threadIdx.x == blockDim.x - 1) vp_last_l = wall_clock64(); } while (0)
 #define STAMPL(ID) do { if (blockIdx.x == 0 && threadIdx.x == blockDim.x - 1) { unsigned long long _t = wall_clock64(); \
         vp_dbg_g[ID] += _t - vp_last_l; vp_last_l = _t; } } while (0)
+// per-wavefront timers (lane 0 of every wave of workgroup 0), into dbg[ID + wave]
+__device__ unsigned long long vp_last_w[16];
+#define STAMPW_BEGIN() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) vp_last_w[threadIdx.x >> 6] = wall_clock64(); } while (0)
+#define STAMPW(ID) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { unsigned long long _t = wall_clock64(); \
+        vp_dbg_g[(ID) + (threadIdx.x >> 6)] += _t - vp_last_w[threadIdx.x >> 6]; vp_last_w[threadIdx.x >> 6] = _t; } } while (0)
 #else
+#define STAMPW_BEGIN() do { } while (0)
+#define STAMPW(ID) do { } while (0)
 #define STAMPL_BEGIN() do { } while (0)
 #define STAMPL(ID) do { } while (0)
 #define STAMPG_BEGIN() do { } while (0)
@@ -1394,6 +1401,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     const int acSplit = min((g.F * 15 / 16) & ~15, (g.F - g.orderPitch) & ~15);  // how much of the sum runs beside YIN
     double acSum = 0.0;
     // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
+    STAMPW_BEGIN();
     {
         const int base = g.toKeep - g.tauMax;
         if (pendingCont >= 0 && (!pitch_can_overlap(g) || c.yinFft)) {      // no free wave: finish the old frame first
@@ -1610,6 +1618,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         }
         STAMPL(26);
     }
+    STAMPW(40);
     __syncthreads();
     // :216-218 (after the old frame's last chunk is out).  With specLpc the residual of the whole frame is
     // written straight into eFrame further down (every entry below toKeep + F), so only the tail is
@@ -1635,31 +1644,34 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         STAMPL(27);
     }
     if (tid < WAVE) {                                                        // :395-402 running sum tmp += yinTemp[k], in order
-        // every lane of wave 0 runs the same chain (full EXEC); eight entries per trip are read
-        // ahead so that only the dependent adds remain on the critical path
-        const int lane = tid;
-        double run = 0.0;
-        const int n8 = (g.tauMax - 1) & ~7;
-        // ping-pong register sets: the next eight entries are requested before the current eight are
-        // chained, so the LDS latency overlaps the dependent adds
-        double va[8], vb[8];
-#define VP_CLOAD(V, K) _Pragma("unroll") for (int u = 0; u < 8; u++) V[u] = L.dY[(K) + u];
-#define VP_CSUM(V, K) { double cs_[8]; _Pragma("unroll") for (int u = 0; u < 8; u++) { run += V[u]; cs_[u] = run; } \
-                        _Pragma("unroll") for (int u = 0; u < 8; u++) L.cum[(K) + u] = cs_[u]; }
-        const int kEnd = 1 + n8;
-        if (n8 > 0) { VP_CLOAD(va, 1) }
-        for (int k0 = 1; k0 < kEnd; k0 += 16) {
-            const bool more1 = k0 + 8 < kEnd;
-            if (more1) { VP_CLOAD(vb, k0 + 8) }
-            VP_CSUM(va, k0)
-            if (more1) {
-                if (k0 + 16 < kEnd) { VP_CLOAD(va, k0 + 16) }
-                VP_CSUM(vb, k0 + 8)
-            }
+        // Sixteen entries per trip, ONE read and ONE write for the whole group: lane l holds entry
+        // k0 + (l & 15) (every 16-lane row the same), and the chain is sixteen v_fmac_f64 with a DPP
+        // row-broadcast operand, cap += entry_u * M_u, where lane l's multiplier M_u is 1.0 for u <= (l & 15)
+        // and 0.0 after.  x * 1.0 + cap rounds exactly like cap + x and x * 0.0 + cap is cap (the entries
+        // are finite sums of squares), so lane l ends the trip holding the running sum up to ITS entry --
+        // the same additions in the same order as the serial loop -- and lane 15's value starts the next
+        // trip.  The per-entry form (uniform reads, same-address writes) spent 2.5x the chain's time on
+        // LDS instructions issued from the chain's own wave (tools/ubench_lds.hip).
+        const int lane = tid, l16 = lane & 15;
+        const double one = 1.0, zero = 0.0;
+        double M[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) M[u] = (l16 >= u) ? 1.0 : 0.0;
+        double cap = 0.0;                                                     // running sum before the trip
+        double vnext = (1 + l16 < g.tauMax) ? L.dY[1 + l16] : 0.0;
+        for (int k0 = 1; k0 < g.tauMax; k0 += 16) {
+            const double v = vnext;
+            { const int kn = k0 + 16 + l16; vnext = (kn < g.tauMax) ? L.dY[kn] : 0.0; }
+            VP_FMAC_BCAST(cap, v, M[0], 0);   VP_FMAC_BCAST(cap, v, M[1], 1);   VP_FMAC_BCAST(cap, v, M[2], 2);   VP_FMAC_BCAST(cap, v, M[3], 3);
+            VP_FMAC_BCAST(cap, v, M[4], 4);   VP_FMAC_BCAST(cap, v, M[5], 5);   VP_FMAC_BCAST(cap, v, M[6], 6);   VP_FMAC_BCAST(cap, v, M[7], 7);
+            VP_FMAC_BCAST(cap, v, M[8], 8);   VP_FMAC_BCAST(cap, v, M[9], 9);   VP_FMAC_BCAST(cap, v, M[10], 10); VP_FMAC_BCAST(cap, v, M[11], 11);
+            VP_FMAC_BCAST(cap, v, M[12], 12); VP_FMAC_BCAST(cap, v, M[13], 13); VP_FMAC_BCAST(cap, v, M[14], 14); VP_FMAC_BCAST(cap, v, M[15], 15);
+            if (k0 + l16 < g.tauMax) L.cum[k0 + l16] = cap;
+            double nxt = zero * zero;                                         // +0.0 in a fresh register
+            asm volatile("s_nop 1" : "+v"(cap), "+v"(nxt));                   // VALU write -> DPP read
+            VP_FMAC_BCAST(nxt, cap, one, 15);                                 // lane 15 of the row: the sum so far
+            cap = nxt;
         }
-#undef VP_CLOAD
-#undef VP_CSUM
-        for (int k = 1 + n8; k < g.tauMax; k++) { run += L.dY[k]; L.cum[k] = run; }
         if (lane == 0) { L.dY[0] = 1.0; L.dY[g.tauMax] = 0.0; }               // :395, guard slot (see oracle)
     }
     __syncthreads();
@@ -1782,50 +1794,55 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
     L.fft = (lds_f64 *)(L.st + 1) + 8;                // [2 << fftLog] only when launched with the FFT extension
 
+    // Everything the block needs from global memory is requested in ONE go (tracker state, the frame in
+    // flight, the voice window of the first steps): three dependent round trips cost three memory latencies.
+    const float *vr = d.voiceRing + (size_t)s * g.inSize;
+    int pS = c.pStart, nChunk = c.nChunk0;
+    auto load_xs = [&](int step, int tid_) {
+        // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double.  Consecutive steps
+        // overlap by all but C samples, so the ring is read once per g.xsSteps steps (once per block
+        // when LDS allows) and the step's window is just an offset into that span.
+        const int nst = min(g.xsSteps, c.nSteps - step);
+        const int span = g.toKeep + g.F + (nst - 1) * g.C;
+        int p0 = ring_pos(c.currCounter, pS - g.toKeep, g.inSize);
+        for (int j = tid_; j < span; j += nt) {
+            int pp = p0 + j;
+            pp -= (pp >= g.inSize) ? g.inSize : 0;                  // span < inSize: one wrap at most
+            xsAll[j] = (double)vr[pp];
+        }
+    };
+    STAMP0(d);
     {   // state in
         const int *src = (const int *)(d.pitch + s);
         lds_i32 *dst = (lds_i32 *)L.st;
         for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
     }
-    STAMP0(d);
-    __syncthreads();
-    const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
-    bool hValid0 = false;
-    if (frameLive0) {
+    if (c.nChunk0 != 0) {
+        // a frame may be in flight (it is if the state says nAn != 0; if not, nothing reads what is loaded
+        // here): its residual, the not yet filtered part of outEFrame (chunks >= nChunk0) and the last
+        // `order` outputs (the IIR's history) are all that later chunks can read
         const double *ge = d.eFrame + (size_t)s * g.eLen, *go = d.outEFrame + (size_t)s * g.F, *gy = d.yFrame + (size_t)s * g.F;
-        // a frame is in flight: its residual, the not yet filtered part of outEFrame (chunks >= nChunk0)
-        // and the last `order` outputs (the IIR's history) are all that later chunks can read
         const int done = c.nChunk0 * g.C;
         for (int i = tid; i < g.eLen; i += nt) L.eF[i] = ge[i];
         for (int i = done + tid; i < g.F; i += nt) L.oE[i] = go[i];
         for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) L.yF[i] = gy[i];
         if ((g.C & 63) == 0 && g.orderPitch < WAVE) {        // the frame's impulse response (block-form IIR)
             if (tid < WAVE) { L.cum[128 + tid] = 0.0; L.cum[128 + WAVE + tid] = d.hImp[(size_t)s * WAVE + tid]; }
-            hValid0 = true;
         }
     }
+    if (c.nSteps > 0) load_xs(0, tid);
     __syncthreads();
+    const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
+    const bool hValid0 = frameLive0 && (g.C & 63) == 0 && g.orderPitch < WAVE;
 
-    const float *vr = d.voiceRing + (size_t)s * g.inSize;
-    int pS = c.pStart, nChunk = c.nChunk0;
     bool qValid = false, hValid = hValid0;
     for (int step = 0; step < c.nSteps; step++) {
         const int tid = vp_tid();
-        // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double.  Consecutive steps
-        // overlap by all but C samples, so the ring is read once per g.xsSteps steps (once per block
-        // when LDS allows) and the step's window is just an offset into that span.
-        if (step % g.xsSteps == 0) {
-            const int nst = min(g.xsSteps, c.nSteps - step);
-            const int span = g.toKeep + g.F + (nst - 1) * g.C;
-            int p0 = ring_pos(c.currCounter, pS - g.toKeep, g.inSize);
-            for (int j = tid; j < span; j += nt) {
-                int pp = p0 + j;
-                pp -= (pp >= g.inSize) ? g.inSize : 0;                  // span < inSize: one wrap at most
-                xsAll[j] = (double)vr[pp];
-            }
+        if (step > 0 && step % g.xsSteps == 0) {
+            load_xs(step, tid);
+            __syncthreads();
         }
         L.xs = xsAll + (step % g.xsSteps) * g.C;
-        __syncthreads();
         STAMP(d, 0);
         // PitchProcess::process (:171-189): a step is [Cont of the running frame] then, when a new
         // frame starts here, [Start]; both feed the same tail psola -> filterIIR -> fillOutputBuffer.
