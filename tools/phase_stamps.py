@@ -50,12 +50,18 @@ def main():
     for i in range(a.steps):
         p.process_device(x[(8 + i) % U], y)
     st = p.debug_stamps()
-    tot = sum(st)
-    print(f"mode={a.mode} S={S} N={N}: per-step microseconds of workgroup 0 (sum {tot / a.steps:.1f})")
+    # ids < 24 are consecutive stretches of thread 0's timeline (they add up to the kernels' duration); ids >= 24 are
+    # timers of OTHER wavefronts or nested stretches, concurrent with the former
+    tot = sum(t for i, t in enumerate(st) if i < 24)
+    print(f"mode={a.mode} S={S} N={N} iir={a.iir}: per-step microseconds of workgroup 0, thread 0's timeline (sum {tot / a.steps:.1f})")
     for i, t in enumerate(st):
-        if t:
-            print(f"  {PHASES.get(i, i):32s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
-
+        if t and i < 24:
+            print(f"  {PHASES.get(i, i):44s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
+    if any(st[24:]):
+        print("concurrent / nested timers:")
+        for i, t in enumerate(st):
+            if t and i >= 24:
+                print(f"  {PHASES.get(i, i):44s} {t / a.steps:9.1f} us")
 
 if __name__ == "__main__":
     main()
