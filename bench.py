@@ -32,6 +32,10 @@ if ROOT not in sys.path:
 FS = 44100.0
 HOP = 256
 ALG_BYTES_PER_FRAME = {"pitch": 3072, "voc": 5120, "both": 5120}
+# fp64 operations per hop-frame of the reference's arithmetic at the default geometry:
+# the secondary, ALU-side sanity line (no MFMA: nothing on this path is a dense contraction)
+ALG_FLOP_PER_FRAME = {"pitch": 0.51e6, "voc": 0.36e6, "both": 0.87e6}
+FP64_VALU_PEAK_TFLOPS = 78.6                                            # vector fp64 peak used by SURVEY.md section 8d (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md
 UNIQUE_BLOCKS = 16                                                      # synthetic input ring, cycled
 
@@ -231,7 +235,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_kernel_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
-                         "note": "path is fp64-VALU/latency-bound (DESIGN.md); HBM fraction is reported as the contract asks"},
+                         "note": "path is fp64-VALU/latency-bound (DESIGN.md); HBM fraction is reported as the contract asks",
+                         "alu_sanity": {"achieved": ALG_FLOP_PER_FRAME[mode] * value / n_gpus / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": ALG_FLOP_PER_FRAME[mode] * value / n_gpus / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                        "what": "reference-arithmetic fp64 ops per hop-frame x frames/s per GPU, default orders"}},
             "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if v[1]},
             "checksum": float(chk.item()),
             f"value_{other}_mode": (frames_per_step_gpu * k2 * n_gpus / dt_other) if dt_other == dt_other else None,
