@@ -77,6 +77,13 @@ int vp_destroy(vp_handle *h);
  * May be called between blocks at any time; lpcPitch only takes effect at the next prepare. */
 int vp_set_params(vp_handle *h, const vp_params *p);
 int vp_get_params(const vp_handle *h, vp_params *p);
+/* One parameter set PER STREAM (each stream of a batch is its own plugin instance with its own treeState).
+ * After prepare; takes effect at the next block.  pitchBool, vocBool and lpcPitch stay per handle (they drive the
+ * block's kernel plan and the prepare-time geometry): `p` must repeat the handle's values for them
+ * (VP_ERR_INVALID_ARG otherwise).  A later vp_set_params() puts every stream back on one common set;
+ * so does a new prepare. */
+int vp_set_stream_params(vp_handle *h, int stream, const vp_params *p);
+int vp_get_stream_params(const vp_handle *h, int stream, vp_params *p);
 void vp_default_params(vp_params *p);
 
 /* VocoderAudioProcessor::prepareToPlay(sampleRate, samplesPerBlock) (PluginProcessor.cpp:144-184)

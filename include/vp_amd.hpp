@@ -67,6 +67,21 @@ public:
         p_ = q;
     }
     const vp_params &parameters() const { return p_; }
+    // one stream's own treeState value (after prepare; pitchBool/vocBool/lpcPitch stay per handle)
+    void setStreamParameter(int stream, const char *id, float v)
+    {
+        vp_params q;
+        check(vp_get_stream_params(h_, stream, &q), "getStreamParams");
+        if (!std::strcmp(id, "gainPitch")) q.gainPitch = v;
+        else if (!std::strcmp(id, "gainVoice")) q.gainVoice = v;
+        else if (!std::strcmp(id, "gainSynth")) q.gainSynth = v;
+        else if (!std::strcmp(id, "gainVoc")) q.gainVoc = v;
+        else if (!std::strcmp(id, "lpcVoice")) q.lpcVoice = (int)v;
+        else if (!std::strcmp(id, "lpcSynth")) q.lpcSynth = (int)v;
+        else if (!std::strcmp(id, "keyPitch")) q.keyPitch = (int)v;
+        else throw Error(VP_ERR_INVALID_ARG, std::string("not a per-stream parameter: ") + id);
+        check(vp_set_stream_params(h_, stream, &q), id);
+    }
 
     void prepareToPlay(double sampleRate, int samplesPerBlock, int nStreams)      // PluginProcessor.cpp:144
     {

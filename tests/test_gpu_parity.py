@@ -544,3 +544,49 @@ def test_long_run_with_random_parameter_schedule():
             _assert_equal(got[s], io[:2], f"block {b} stream {s} (schedule {sched})")
     ub = np.sum([o.ub_counters() for o in os_], axis=0)
     assert list(p.ub_counters()) == list(ub)
+
+
+def test_per_stream_parameters():
+    """Every stream of a batch is its own plugin instance: per-stream key / orders / gains, set before and between
+    blocks, against one oracle per stream with that stream's values."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    S, N, B = 5, 1024, 30
+    x = _streams(S, N * B)
+    per = [dict(), dict(keyPitch=3, gainPitch=-6.0), dict(lpcVoice=16, lpcSynth=12, gainVoc=-12.0),
+           dict(keyPitch=0, gainVoice=-10.0, gainSynth=-20.0), dict(keyPitch=7, lpcVoice=100, lpcSynth=30)]
+    later = {12: (1, "keyPitch", 9), 17: (2, "gainVoc", 3.0), 21: (4, "lpcVoice", 8)}
+    p = BatchVocoderProcessor()
+    with pytest.raises(VpError):
+        p.setStreamParameter(0, "keyPitch", 2)                      # before prepare
+    p.prepareToPlay(FS, N, S)
+    os_ = []
+    for s_, kv in enumerate(per):
+        o = O.OracleStream()
+        o.prepare_to_play(FS, N)
+        for k, v in kv.items():
+            p.setStreamParameter(s_, k, v)
+            o.set_param(k, v)
+        os_.append(o)
+    assert p.getStreamParameter(1, "keyPitch") == 3 and p.getStreamParameter(0, "keyPitch") == 12
+    with pytest.raises(VpError):
+        p.setStreamParameter(0, "pitchBool", 0)                     # per handle only
+    with pytest.raises(VpError):
+        p.setStreamParameter(S, "keyPitch", 1)                      # no such stream
+    for b in range(B):
+        if b in later:
+            s_, k, v = later[b]
+            p.setStreamParameter(s_, k, v)
+            os_[s_].set_param(k, v)
+        if b == 25:                                                  # the handle-wide set puts every stream on one set again
+            p.setParameter("keyPitch", 5)
+            for o in os_:
+                for k, v in dict(gainPitch=0.0, gainVoice=-60.0, gainSynth=-60.0, gainVoc=0.0, lpcVoice=40, lpcSynth=5).items():
+                    o.set_param(k, v)
+                o.set_param("keyPitch", 5)
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        got = p.process(blk)
+        for s_ in range(S):
+            io = blk[s_].copy()
+            os_[s_].process_block(io)
+            _assert_equal(got[s_], io[:2], f"block {b} stream {s_}")

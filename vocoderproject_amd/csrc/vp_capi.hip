@@ -34,6 +34,10 @@ struct vp_handle {
     size_t vocLds = 0, pitchLds = 0;
     bool prof = false;
     int iirMode = 0, yinMode = 0;
+    // per-stream parameter overrides (vp_set_stream_params): host copy, device copy, upload pending
+    std::vector<vp_params> sparams;             // [S] what each stream's treeState holds
+    std::vector<VpStreamParams> spHost;         // [S] the same in kernel form (float gains applied), staging for the upload
+    bool perStream = false, spDirty = false;    // any stream differs from `params` / device copy out of date
     struct EvPair { hipEvent_t a, b; int slot; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> evPool;
@@ -153,6 +157,36 @@ extern "C" int vp_set_params(vp_handle *h, const vp_params *p)
 {
     if (!h || !p || !params_valid(p)) return VP_ERR_INVALID_ARG;
     h->params = *p;
+    h->perStream = false;                       // one set for every stream again
+    for (auto &q : h->sparams) q = *p;
+    h->spDirty = true;
+    return VP_OK;
+}
+
+static void fill_stream_params(VpStreamParams &o, const vp_params &P);
+
+extern "C" int vp_set_stream_params(vp_handle *h, int stream, const vp_params *p)
+{
+    if (!h || !p || !params_valid(p)) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (stream < 0 || stream >= h->g.S) { h->lastError = "stream index out of range"; return VP_ERR_INVALID_ARG; }
+    // the switches that drive the (host-side) chunk and window schedulers, and the prepare-time order, are per handle
+    if (p->pitchBool != h->params.pitchBool || p->vocBool != h->params.vocBool || p->lpcPitch != h->params.lpcPitch) {
+        h->lastError = "pitchBool, vocBool and lpcPitch are per handle (vp_set_params); per-stream sets must repeat them";
+        return VP_ERR_INVALID_ARG;
+    }
+    h->sparams[stream] = *p;
+    h->perStream = true;
+    h->spDirty = true;
+    return VP_OK;
+}
+
+extern "C" int vp_get_stream_params(const vp_handle *h, int stream, vp_params *p)
+{
+    if (!h || !p) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (stream < 0 || stream >= h->g.S) return VP_ERR_INVALID_ARG;
+    *p = h->perStream ? h->sparams[stream] : h->params;
     return VP_OK;
 }
 
@@ -403,6 +437,9 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     h->outCounter = 0;
     h->currCounter = g.toKeep;
     h->vStart = 0; h->pStart = 0; h->nChunk = 0;                             // VocoderProcess.cpp:39, PitchProcess.cpp:85,90
+    h->sparams.assign((size_t)S, h->params);                                 // prepare starts every stream from the handle's set
+    h->spHost.assign((size_t)S, VpStreamParams{});
+    h->perStream = false; h->spDirty = true;                                 // the fresh (zeroed) state needs them
     h->prepared = true;
     (void)hipDeviceSynchronize();
     return VP_OK;
@@ -441,6 +478,18 @@ struct ProfScope {
     }
 };
 
+// float gains via decibelsToGain computed in float, switches of the dry paths (PluginProcessor.cpp:214-230)
+static void fill_stream_params(VpStreamParams &o, const vp_params &P)
+{
+    o.orderVoice = P.lpcVoice; o.orderSynth = P.lpcSynth; o.key = P.keyPitch; o.pad = 0;
+    o.dryOn = ((double)P.gainVoice > -59.0);                                 // PluginProcessor.cpp:226
+    o.synthOn = ((double)P.gainSynth > -59.0);                               // :229
+    o.gainPitch = (double)db_to_gain_f(P.gainPitch);
+    o.gainVoc = (double)db_to_gain_f(P.gainVoc);
+    o.gainVoice = (double)db_to_gain_f(P.gainVoice);
+    o.gainSynth = (double)db_to_gain_f(P.gainSynth);
+}
+
 static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace)
 {
     const VpGeom &g = h->g;
@@ -449,16 +498,17 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     VpCall c;
     memset(&c, 0, sizeof c);
     c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
-    c.orderVoice = P.lpcVoice; c.orderSynth = P.lpcSynth; c.key = P.keyPitch;
     c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
     c.iirFast = h->iirMode;
     c.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
-    c.dryOn = ((double)P.gainVoice > -59.0);                                 // PluginProcessor.cpp:226
-    c.synthOn = ((double)P.gainSynth > -59.0);                               // :229
-    c.gainPitch = (double)db_to_gain_f(P.gainPitch);
-    c.gainVoc = (double)db_to_gain_f(P.gainVoc);
-    c.gainVoice = (double)db_to_gain_f(P.gainVoice);
-    c.gainSynth = (double)db_to_gain_f(P.gainSynth);
+    if (h->spDirty) {
+        // orders, key, gains and the dry-path switches travel in each stream's device state (VpPitchState::sp);
+        // rewritten here, stream-ordered in front of this block's kernels, whenever a set call changed them
+        for (int i = 0; i < g.S; i++) fill_stream_params(h->spHost[i], h->sparams[i]);
+        HIPCHK(h, hipMemcpy2DAsync(&h->d.pitch[0].sp, sizeof(VpPitchState), h->spHost.data(), sizeof(VpStreamParams),
+                                   sizeof(VpStreamParams), (size_t)g.S, hipMemcpyHostToDevice, st));
+        h->spDirty = false;
+    }
     // VocoderProcess::process (VocoderProcess.cpp:173-183): windows while startSample < N
     c.vStart = h->vStart;
     c.nWin = 0;

@@ -40,11 +40,17 @@ struct VpCall {
     int inCounter, outCounter, currCounter;
     int vStart, nWin;            // vocoder windows start at vStart + j*h, j < nWin
     int pStart, nChunk0, nSteps; // pitch chunk steps start at pStart + j*C
-    int orderVoice, orderSynth, key;
-    int pitchOn, vocOn, dryOn, synthOn, inplace;
+    int pitchOn, vocOn, inplace;
     int fuseIngest, fuseEmit;    // this launch also runs the ingest+gate prologue / the emit epilogue
     int yinFft;                  // 1: FFT accelerator for the YIN difference function + LPC autocorrelation
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
+};
+
+// The per-block parameters of ONE stream (each stream is a plugin instance with its own treeState).  They live in
+// the stream's device state -- the pitch kernel stages that in LDS anyway -- and are rewritten by the host whenever
+// vp_set_params / vp_set_stream_params changed them (stream-ordered, in front of the block's kernels).
+struct VpStreamParams {
+    int orderVoice, orderSynth, key, dryOn, synthOn, pad;
     double gainPitch, gainVoc, gainVoice, gainSynth;   // (double) of the float gains
 };
 
@@ -55,6 +61,7 @@ struct VpPitchState {
     int nAn, nSt, nPrevAn, nPrevSt;
     int anMarks[VP_MARKS], stMarks[VP_MARKS], prevAnMarks[VP_MARKS], prevStMarks[VP_MARKS];
     double a[VP_ORDER_MAX + 1];
+    VpStreamParams sp;
 };
 
 struct VpDev {

@@ -71,7 +71,9 @@ __device__ __forceinline__ int vp_tid()
     return t;
 }
 
-__device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out);
+typedef __attribute__((address_space(3))) VpPitchState lds_state;
+__device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
+                                           const lds_state *stl = nullptr);
 
 __device__ __forceinline__ int ring_pos(int curr, int idx, int inSize)
 {
@@ -679,7 +681,8 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
     const int wave = tid >> 6, lane = tid & 63, nWaves = blockDim.x >> 6;
     if (!(d.gate[s * 2 + 0] && d.gate[s * 2 + 1])) return;     // :199-204, whole workgroup
 
-    const int W = g.W, oV = c.orderVoice, oS = c.orderSynth;
+    const VpStreamParams sp = d.pitch[s].sp;              // this stream's treeState values (one uniform read)
+    const int W = g.W, oV = sp.orderVoice, oS = sp.orderSynth;
     lds_f64 *sm = (lds_f64 *)smem;
     lds_f64 *win = sm;                        // [W] shared by all waves
     lds_f64 *hist = win + W;                  // [2][10] EeVoiceArr, EeSynthArr
@@ -816,7 +819,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         __syncthreads();
         STAMP(d, 22);
         if (active)                                      // gainVoc * out[i] * stWindow[i] (:291-295)
-            for (int i = lane; i < W; i += WAVE) B[i] = c.gainVoc * B[i] * win[i];
+            for (int i = lane; i < W; i += WAVE) B[i] = sp.gainVoc * B[i] * win[i];
         __syncthreads();
 
         // overlap-add in gather form: every output sample adds its covering windows in window order,
@@ -917,7 +920,6 @@ __device__ __forceinline__ int bitrev(int k, int logM) { return (int)(__brev((un
 //      yF   [F]         yFrame
 //      dY   [tauMax+1]  yinTemp (+ guard slot), cum [tauMax]
 //      r, aPrev [101]
-typedef __attribute__((address_space(3))) VpPitchState lds_state;
 typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
     lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *htab, *fft;
@@ -1087,7 +1089,8 @@ __device__ __forceinline__ void place_st_marks(const VpGeom &g, const VpCall &c,
     st->nStMarksOv = nOv;
     st->prevClosestFreq = st->closestFreq;
     if (st->pitch > 1) {
-        st->closestFreq = notes_closest(d.notes + (size_t)c.key * VP_NOTES_STRIDE, d.notesN[c.key], st->pitch);
+        const int key = st->sp.key;
+        st->closestFreq = notes_closest(d.notes + (size_t)key * VP_NOTES_STRIDE, d.notesN[key], st->pitch);
         st->beta = st->closestFreq / st->pitch;
         st->periodNew = (int)round(st->period / st->beta);
     } else {
@@ -1321,9 +1324,10 @@ __device__ __forceinline__ void pitch_fill_output_wave(const VpGeom &g, const Vp
                                                        int nChunk, int pS, int s)
 {
     double *acc = d.outAcc + (size_t)s * g.outSize;
+    const double gainPitch = L.st->sp.gainPitch;
     for (int i = vp_tid() & 63; i < g.C; i += WAVE) {
         int pos = (c.outCounter + pS + i) % g.outSize;
-        acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
+        acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * gainPitch;
     }
 }
 
@@ -1332,9 +1336,10 @@ __device__ __forceinline__ void pitch_fill_output(const VpGeom &g, const VpCall 
 {
     // PitchProcess::fillOutputBuffer (PitchProcess.cpp:328-342)
     double *acc = d.outAcc + (size_t)s * g.outSize;
+    const double gainPitch = L.st->sp.gainPitch;
     for (int i = vp_tid(); i < g.C; i += blockDim.x) {
         int pos = (c.outCounter + pS + i) % g.outSize;
-        acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * c.gainPitch;
+        acc[pos] += L.yF[i + nChunk * g.C] * d.pitchStWin[i + nChunk * g.C] * gainPitch;
     }
     __syncthreads();
     STAMP(d, 9);
@@ -1897,7 +1902,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     STAMP(d, 11);
     if (c.fuseEmit) {
         __syncthreads();
-        emit_block(g, c, d, out);
+        emit_block(g, c, d, out, L.st);
     }
 }
 
@@ -1939,7 +1944,8 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall 
 // K3: emit.  addDryVoice / addSynth (MyBuffer.cpp:309-448) + fillOutputBuffer + clearOutput
 // (MyBuffer.cpp:113-133, 218-228).  out[ch] = float(((acc + dry) + synth_ch)); the consumed region of
 // the accumulator is zeroed.
-__device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out)
+__device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
+                                           const lds_state *stl)
 {
     const int s = blockIdx.x;
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
@@ -1947,13 +1953,17 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
     const float *sr1 = sr0 + g.inSize;
     double *acc = d.outAcc + (size_t)s * g.outSize;
     float *o = out + (size_t)s * (c.inplace ? 3 : 2) * g.N;
+    // the stream's dry-path switches and gains: from the state the pitch kernel holds in LDS, else from HBM
+    const int dryOn = stl ? stl->sp.dryOn : d.pitch[s].sp.dryOn, synthOn = stl ? stl->sp.synthOn : d.pitch[s].sp.synthOn;
+    const double gainVoice = stl ? stl->sp.gainVoice : d.pitch[s].sp.gainVoice;
+    const double gainSynth = stl ? stl->sp.gainSynth : d.pitch[s].sp.gainSynth;
     for (int i = threadIdx.x; i < g.N; i += blockDim.x) {
         int pos = (c.outCounter + i) % g.outSize;
         int pin = (c.currCounter + i) % g.inSize;
         double v = acc[pos];
-        if (c.dryOn) v += (double)vr[pin] * c.gainVoice;
+        if (dryOn) v += (double)vr[pin] * gainVoice;
         double l = v, r = v;
-        if (c.synthOn) { l += (double)sr0[pin] * c.gainSynth; r += (double)sr1[pin] * c.gainSynth; }
+        if (synthOn) { l += (double)sr0[pin] * gainSynth; r += (double)sr1[pin] * gainSynth; }
         o[i] = (float)l;
         o[g.N + i] = (float)r;
         if (c.inplace) o[2 * g.N + i] = 0.0f;

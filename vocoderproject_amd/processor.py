@@ -77,6 +77,9 @@ def load_library():
     L.vp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]
     L.vp_kernel_slot_name.argtypes = [C.c_int]
     L.vp_kernel_slot_name.restype = C.c_char_p
+    if hasattr(L, "vp_set_stream_params"):            # absent only from older builds loaded through VP_AMD_LIB (tools/ab.sh)
+        L.vp_set_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vp_get_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.vp_pitch_kernel_name.argtypes = [C.c_void_p]
     L.vp_pitch_kernel_name.restype = C.c_char_p
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
@@ -144,6 +147,21 @@ class BatchVocoderProcessor:
 
     def getParameter(self, pid):
         return getattr(self._p, pid)
+
+    def setStreamParameter(self, stream, pid, value):
+        """One stream's own value of a parameter (each stream is a plugin instance with its own treeState).  After
+        prepare; pitchBool, vocBool and lpcPitch stay per handle.  setParameter() puts all streams back on one set."""
+        if pid not in PARAM_IDS:
+            raise KeyError(pid)
+        q = VpParams()
+        self._chk(self.L.vp_get_stream_params(self.h, int(stream), C.byref(q)))
+        setattr(q, pid, type(getattr(q, pid))(value))
+        self._chk(self.L.vp_set_stream_params(self.h, int(stream), C.byref(q)))
+
+    def getStreamParameter(self, stream, pid):
+        q = VpParams()
+        self._chk(self.L.vp_get_stream_params(self.h, int(stream), C.byref(q)))
+        return getattr(q, pid)
 
     def set_iir_mode(self, mode):
         """"exact" (default, bit-identical to the reference's summation order) or "fast" (VP_IIR_FAST)."""
