@@ -137,6 +137,8 @@ def main():
                          "configuration; 'exact' (bit-identical to the oracle) is timed beside it as value_exact_mode")
     ap.add_argument("--single-mode", action="store_true",
                     help="do not time the other IIR mode or the STFT kernel (for profiler runs: one kernel population)")
+    ap.add_argument("--blocks-per-step", type=int, default=1,
+                    help="host blocks of N samples handed over per step (vp_process_blocks_device; one launch in pitch mode)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -168,11 +170,17 @@ def main():
     U = UNIQUE_BLOCKS
     x = make_streams(S, N * U, fs=FS, first_stream=rank * S, device=dev)          # [S][3][U*N]
     x = x.view(S, 3, U, N).permute(2, 0, 1, 3).contiguous()                     # [U][S][3][N]
-    y = torch.empty((S, 2, N), dtype=torch.float32, device=dev)
+    BPS = args.blocks_per_step
+    assert 1 <= BPS <= U and U % BPS == 0
+    y = torch.empty((BPS, S, 2, N), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def step(i):
-        p.process_device(x[i % U], y, stream.cuda_stream)
+        if BPS == 1:
+            p.process_device(x[i % U], y[0], stream.cuda_stream)
+        else:
+            b0 = (i * BPS) % U
+            p.process_blocks_device(x[b0:b0 + BPS], y, stream.cuda_stream)
 
     def timed(mode_iir, steps, warmup):
         p.set_iir_mode(mode_iir)
@@ -201,16 +209,36 @@ def main():
     dt_other = float("nan")
     if not args.single_mode:
         dt_other, _ = timed(other, k2, max(2, args.warmup // 4))
+    # a second secondary figure: the same blocks handed over eight at a time (vp_process_blocks_device: one launch per eight
+    # blocks in pitch mode, state stays on chip in between); reported beside `value`, never as it
+    MB, k3 = 8, max(4, args.steps // 16)
+    dt_mb = float("nan")
+    if not args.single_mode and BPS == 1 and mode == "pitch" and U % MB == 0:
+        ymb = torch.empty((MB, S, 2, N), dtype=torch.float32, device=dev)
+        p.set_iir_mode(args.iir)
+        for i in range(2):
+            p.process_blocks_device(x[0:MB], ymb, stream.cuda_stream)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(k3):
+            b0 = (i * MB) % U
+            p.process_blocks_device(x[b0:b0 + MB], ymb, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        dt_mb = time.perf_counter() - t0
     dt, prof = timed(args.iir, args.steps, args.warmup)
 
-    tt = torch.tensor([dt, dt_other], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, dt_other, dt_mb], dtype=torch.float64, device=dev)
     chk = y.double().abs().sum().view(1)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)          # the only collective: a checksum of the outputs
-    dt, dt_other = float(tt[0].item()), float(tt[1].item())
+    dt, dt_other, dt_mb = float(tt[0].item()), float(tt[1].item()), float(tt[2].item())
 
-    frames_per_step_gpu = S * N // HOP
+    frames_per_step_gpu = S * N * BPS // HOP
     total_frames = frames_per_step_gpu * args.steps * n_gpus
     value = total_frames / dt
 
@@ -229,8 +257,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
-                                   f", 1024-pt frames hop 256, host block N={N}",
-                       "streams_per_gpu": S, "block": N, "mode": mode, "iir_mode": args.iir, "frames_per_step": frames_per_step_gpu * n_gpus,
+                                   f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
+                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "frames_per_step": frames_per_step_gpu * n_gpus,
                        "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -242,10 +270,11 @@ def main():
             "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if v[1]},
             "checksum": float(chk.item()),
             f"value_{other}_mode": (frames_per_step_gpu * k2 * n_gpus / dt_other) if dt_other == dt_other else None,
+            "value_8_blocks_per_call": ((S * N * MB // HOP) * k3 * n_gpus / dt_mb) if dt_mb == dt_mb else None,
         }
         if not args.single_mode:
             out["stft_kernel"] = stft_figure(dev, S)
-        out["roofline"]["traffic"] = measured_traffic(mode, S, N, args.iir)
+        out["roofline"]["traffic"] = measured_traffic(mode, S, N, args.iir) if BPS == 1 else None
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
         print(json.dumps(out))

@@ -111,6 +111,12 @@ int vp_process_block_inplace(vp_handle *h, float *io);
  * the layouts above; kernels are enqueued on `hip_stream` (a hipStream_t, may be NULL = default
  * stream) and the call returns without synchronising. */
 int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void *hip_stream);
+/* n_blocks consecutive processBlock() calls at once (offline rendering, servers with audio queued up):
+ * d_in float [n_blocks][n_streams][3][N], d_out float [n_blocks][n_streams][2][N], i.e. block b's slabs are what
+ * vp_process_block_device would take.  Results are identical to n_blocks single calls.  With the pitch corrector alone
+ * enabled the blocks run in ONE launch (tracker state and the frame in flight stay on chip between them); other
+ * plans are issued block by block.  Parameters are read once, at entry. */
+int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream);
 
 /* Arithmetic of the two all-pole synthesis filters (VocoderProcess.cpp:277-286, PitchProcess.cpp:307-322).
  * VP_IIR_EXACT (default): the reference's summation order, output bit-identical to the CPU restatement.

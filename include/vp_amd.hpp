@@ -101,6 +101,11 @@ public:
     {
         check(vp_process_block_device(h_, dIn, dOut, hipStream), "processBlockDevice");
     }
+    // nBlocks consecutive processBlock() calls at once: dIn [nBlocks][streams][3][N], dOut [nBlocks][streams][2][N]
+    void processBlocksDevice(const float *dIn, float *dOut, int nBlocks, void *hipStream = nullptr)
+    {
+        check(vp_process_blocks_device(h_, dIn, dOut, nBlocks, hipStream), "processBlocksDevice");
+    }
     int getLatencySamples() const { return vp_get_latency(h_); }                   // :183
     BufferView bufferView() const
     {

@@ -590,3 +590,41 @@ def test_per_stream_parameters():
             io = blk[s_].copy()
             os_[s_].process_block(io)
             _assert_equal(got[s_], io[:2], f"block {b} stream {s_}")
+
+
+@pytest.mark.parametrize("iir", ["exact", "fast"])
+def test_multi_block_launch_equals_block_by_block(iir):
+    """vp_process_blocks_device: B blocks in one launch give exactly what B single-block calls give (and, in exact
+    mode, what the oracle gives), gate crossings and unvoiced stretches included; other plans fall back to single calls."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 6, 1024, 24
+    x = _edge_streams(N * B)[:S]
+    xb = torch.from_numpy(np.ascontiguousarray(x.reshape(S, 3, B, N).transpose(2, 0, 1, 3))).cuda()      # [B][S][3][N]
+
+    def run(split, **params):
+        p = BatchVocoderProcessor(**params)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode(iir)
+        y = torch.empty((B, S, 2, N), dtype=torch.float32, device="cuda")
+        b = 0
+        for n in split:
+            p.process_blocks_device(xb[b:b + n].contiguous(), y[b:b + n])
+            b += n
+        assert b == B
+        torch.cuda.synchronize()
+        return y.cpu().numpy(), [p.pitch_state(s_) for s_ in range(S)], p.ub_counters()
+
+    for params in (dict(vocBool=0), dict()):                       # pitch only (one launch per group) / both (fallback)
+        ref, st_ref, ub_ref = run([1] * B, **params)
+        for split in ([B], [5, 1, 7, 11], [2] * 12):
+            got, st, ub = run(split, **params)
+            _assert_equal(got, ref, f"{params} split {split}")
+            assert ub == ub_ref
+            for s_ in range(S):
+                for k in st_ref[s_]:
+                    assert np.array_equal(st[s_][k], st_ref[s_][k]), (s_, k)
+    if iir == "exact":
+        want = _oracle_run(x, N, dict(vocBool=0))
+        got, _, _ = run([B], vocBool=0)
+        _assert_equal(got.transpose(1, 2, 0, 3).reshape(S, 2, B * N), want, "multi-block vs oracle")

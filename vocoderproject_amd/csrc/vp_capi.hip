@@ -386,6 +386,10 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                                   (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_fast, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
+    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_fast_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_lite, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_lite_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
     HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_vocoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vocLds));
@@ -490,7 +494,7 @@ static void fill_stream_params(VpStreamParams &o, const vp_params &P)
     o.gainSynth = (double)db_to_gain_f(P.gainSynth);
 }
 
-static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace)
+static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace, int nBlocks = 1)
 {
     const VpGeom &g = h->g;
     const vp_params P = h->params;                                           // snapshot at call entry
@@ -500,6 +504,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
     c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
     c.iirFast = h->iirMode;
+    c.nBlocks = 1;
     c.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
     if (h->spDirty) {
         // orders, key, gains and the dry-path switches travel in each stream's device state (VpPitchState::sp);
@@ -536,32 +541,37 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
         if (runPitch) {
             VpCall cp = c;
             cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
+            cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
             ProfScope ps(h, st, 2);
             // large batches: the register-light build lets two workgroups share a CU (needs <= 80 KB LDS each and
             // no big register-resident exact-IIR instantiation)
             const bool lite = pitch_lite(h, cp.iirFast != 0, cp.yinFft != 0);
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
+            if (nBlocks > 1) k = cp.iirFast ? vp_k_pitch_fast_multi : vp_k_pitch_multi;       // never with `lite` (see the caller)
             hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);
         }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
 
-    // counters: VocoderProcess.cpp:176-182, PitchProcess.cpp:169-195, MyBuffer.cpp:129-132
-    if (c.vocOn) h->vStart = h->vStart + c.nWin * g.h - g.N;
-    if (c.pitchOn) {
-        int nChunk = h->nChunk;
-        for (int i = 0; i < c.nSteps; i++) {
-            if (nChunk % g.cpf == g.cpf - 1) nChunk = 1 % g.cpf;
-            else nChunk += 1;
+    // counters: VocoderProcess.cpp:176-182, PitchProcess.cpp:169-195, MyBuffer.cpp:129-132 (once per block handled)
+    for (int b = 0; b < nBlocks; b++) {
+        if (c.vocOn) h->vStart = h->vStart + c.nWin * g.h - g.N;
+        if (c.pitchOn) {
+            const int nSteps = (h->pStart < g.N) ? (g.N - h->pStart + g.C - 1) / g.C : 0;
+            int nChunk = h->nChunk;
+            for (int i = 0; i < nSteps; i++) {
+                if (nChunk % g.cpf == g.cpf - 1) nChunk = 1 % g.cpf;
+                else nChunk += 1;
+            }
+            h->nChunk = nChunk;
+            h->pStart = h->pStart + nSteps * g.C - g.N;
         }
-        h->nChunk = nChunk;
-        h->pStart = h->pStart + c.nSteps * g.C - g.N;
+        h->outCounter = (h->outCounter + g.N) % g.outSize;
+        h->inCounter = (h->inCounter + g.N) % g.inSize;
+        h->currCounter = (h->currCounter + g.N) % g.inSize;
     }
-    h->outCounter = (h->outCounter + g.N) % g.outSize;
-    h->inCounter = (h->inCounter + g.N) % g.inSize;
-    h->currCounter = (h->currCounter + g.N) % g.inSize;
     return VP_OK;
 }
 
@@ -571,6 +581,23 @@ extern "C" int vp_process_block_device(vp_handle *h, const float *d_in, float *d
     if (!h->prepared) return VP_ERR_NOT_PREPARED;
     if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0);
+}
+
+extern "C" int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream)
+{
+    if (!h || !d_in || !d_out || n_blocks < 1) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    const vp_params &P = h->params;
+    const bool fast = h->iirMode == VP_IIR_FAST, fft = h->yinMode == VP_YIN_FFT && h->g.fftLog > 0;
+    if (P.pitchBool && !P.vocBool && n_blocks > 1 && !pitch_lite(h, fast, fft))   // one launch: state stays on chip between the blocks
+        return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks);
+    const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
+    for (int b = 0; b < n_blocks; b++) {                       // other plans: block by block
+        int rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0);
+        if (rc) return rc;
+    }
+    return VP_OK;
 }
 
 extern "C" int vp_process_block(vp_handle *h, const float *in, float *out)

@@ -44,6 +44,8 @@ struct VpCall {
     int fuseIngest, fuseEmit;    // this launch also runs the ingest+gate prologue / the emit epilogue
     int yinFft;                  // 1: FFT accelerator for the YIN difference function + LPC autocorrelation
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
+    int nBlocks;                 // pitch kernel with both fusions: consecutive blocks handled by this launch (>= 1);
+                                 // the counters above describe the first, the kernel advances them itself
 };
 
 // The per-block parameters of ONE stream (each stream is a plugin instance with its own treeState).  They live in

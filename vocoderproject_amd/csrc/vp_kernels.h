@@ -10,6 +10,8 @@ __global__ void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict_
 __global__ void vp_k_pitch_lite(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_lite_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_fast_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
 
 // bytes of dynamic LDS vp_k_pitch needs for a geometry

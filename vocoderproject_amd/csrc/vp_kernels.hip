@@ -73,7 +73,7 @@ __device__ __forceinline__ int vp_tid()
 
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
-                                           const lds_state *stl = nullptr);
+                                           const lds_state *stl = nullptr, int boff = 0);
 
 __device__ __forceinline__ int ring_pos(int curr, int idx, int inSize)
 {
@@ -109,7 +109,8 @@ __device__ __forceinline__ double wave_sum(double v)
 // "sum_seq < gateThrSum" (gateThrSum is found on the host by bisection through the same libm
 // calls).  A tree sum T differs from the sequential one by at most ~2 n eps T, so T decides unless
 // it is within that band of the threshold, in which case one lane redoes the exact sequential sum.
-__device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in)
+__device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in,
+                                                  int boff = 0)
 {
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     float *vr = d.voiceRing + (size_t)s * g.inSize;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
     float *sr1 = sr0 + g.inSize;
     const float *xin = in + (size_t)s * 3 * g.N;
     for (int i = tid; i < g.N; i += nt) {
-        int p = (c.inCounter + i) % g.inSize;
+        int p = (c.inCounter + boff + i) % g.inSize;
         vr[p] = xin[i];
         sr0[p] = xin[g.N + i];
         sr1[p] = xin[2 * g.N + i];
@@ -1773,11 +1774,17 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     return 1;
 }
 
-template <bool LITE, bool FAST>
-__device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in,
-                                                  float *__restrict__ out, double *smem)
+template <bool LITE, bool FAST, bool MULTI>
+__device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in0,
+                                                  float *__restrict__ out0, double *smem)
 {
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    // the block in hand (vp_process_blocks_device runs several per launch): its offset in samples from the first one
+    // -- the ring and output counters of `c` describe the first block, later ones are that much further on --, its
+    // chunk-step count and its I/O slabs
+    int boff = 0, nSteps = c.nSteps;
+    const float *in = in0;
+    float *out = out0;
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     PitchLds L;
     // voice window of g.xsSteps consecutive chunk steps; shifted by one double when needed so that
@@ -1807,9 +1814,9 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         // voice samples idx in [pS - toKeep, pS + F) of this step, widened to double.  Consecutive steps
         // overlap by all but C samples, so the ring is read once per g.xsSteps steps (once per block
         // when LDS allows) and the step's window is just an offset into that span.
-        const int nst = min(g.xsSteps, c.nSteps - step);
+        const int nst = min(g.xsSteps, nSteps - step);
         const int span = g.toKeep + g.F + (nst - 1) * g.C;
-        int p0 = ring_pos(c.currCounter, pS - g.toKeep, g.inSize);
+        int p0 = ring_pos(c.currCounter, boff + pS - g.toKeep, g.inSize);
         for (int j = tid_; j < span; j += nt) {
             int pp = p0 + j;
             pp -= (pp >= g.inSize) ? g.inSize : 0;                  // span < inSize: one wrap at most
@@ -1835,13 +1842,30 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
             if (tid < WAVE) { L.cum[128 + tid] = 0.0; L.cum[128 + WAVE + tid] = d.hImp[(size_t)s * WAVE + tid]; }
         }
     }
-    if (c.nSteps > 0) load_xs(0, tid);
+    if (nSteps > 0) load_xs(0, tid);
     __syncthreads();
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
     const bool hValid0 = frameLive0 && (g.C & 63) == 0 && g.orderPitch < WAVE;
 
     bool qValid = false, hValid = hValid0;
-    for (int step = 0; step < c.nSteps; step++) {
+    // vp_process_blocks_device: several consecutive blocks in this launch.  The tracker state and the frame in flight
+    // stay in LDS between them; per block only the input is ingested (rings, gate), the voice window staged and the
+    // output emitted -- exactly what separate launches would do, minus their state round trips.
+    // (a separate build, MULTI: the extra loop level costs the single-block kernels 3 % through register allocation)
+    for (int blk = 0; blk < (MULTI ? c.nBlocks : 1); blk++) {
+    if (MULTI && blk > 0) {
+        // MyBuffer.cpp:129-132 and PitchProcess.cpp:166-196, as the host does between calls
+        boff += g.N;
+        pS -= g.N;
+        nSteps = (pS < g.N) ? (g.N - pS + g.C - 1) / g.C : 0;
+        in += (size_t)g.S * 3 * g.N;
+        out += (size_t)g.S * (c.inplace ? 3 : 2) * g.N;
+        __syncthreads();                              // the previous block's emit has read what the ingest overwrites
+        ingest_gate_block(g, c, d, in, boff);
+        if (nSteps > 0) load_xs(0, tid);
+        __syncthreads();
+    }
+    for (int step = 0; step < nSteps; step++) {
         const int tid = vp_tid();
         if (step > 0 && step % g.xsSteps == 0) {
             load_xs(step, tid);
@@ -1870,7 +1894,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre<LITE, FAST>(g, c, d, L, pS, s, pendingCont, hValid);
+                mode = pitch_chunk_start_pre<LITE, FAST>(g, c, d, L, boff + pS, s, pendingCont, hValid);   // pS: output position only
                 hValid = (mode != 0) && (g.C & 63) == 0 && g.orderPitch < WAVE;    // computed there for the new coefficients
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
@@ -1878,12 +1902,17 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 psola(g, d, L, nC, pS, qValid);
                 pitch_iir<LITE, FAST>(g, d, L, nC, hValid);
             }
-            if (mode >= 1) pitch_fill_output(g, c, d, L, nC, pS, s);
+            if (mode >= 1) pitch_fill_output(g, c, d, L, nC, boff + pS, s);
             __syncthreads();
         }
         nChunk += 1;
         __syncthreads();
         pS += g.C;
+    }
+    if (MULTI && blk + 1 < c.nBlocks) {               // not the last block: its output goes out now
+        __syncthreads();
+        emit_block(g, c, d, out, L.st, boff);
+    }
     }
 
     {   // state out
@@ -1902,7 +1931,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     STAMP(d, 11);
     if (c.fuseEmit) {
         __syncthreads();
-        emit_block(g, c, d, out, L.st);
+        emit_block(g, c, d, out, L.st, boff);
     }
 }
 
@@ -1913,14 +1942,29 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
 __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false, false>(g, c, d, in, out, smem);
 }
 
 __global__ __launch_bounds__(512) void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                        float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, true>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, true, false>(g, c, d, in, out, smem);
+}
+
+// vp_process_blocks_device: the same two, looping over c.nBlocks consecutive blocks (state stays in LDS between them)
+__global__ __launch_bounds__(512) void vp_k_pitch_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                        float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, false, true>(g, c, d, in, out, smem);
+}
+
+__global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                             float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, true, true>(g, c, d, in, out, smem);
 }
 
 // Register-light build of the same kernel (<= 128 VGPRs: two 512-thread workgroups per CU), selected by the
@@ -1930,14 +1974,14 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite(VpGeom g, VpCall c, Vp
                                                            float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, false, false>(g, c, d, in, out, smem);
 }
 
 __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                                 float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true, true>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, true, false>(g, c, d, in, out, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1945,7 +1989,7 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall 
 // (MyBuffer.cpp:113-133, 218-228).  out[ch] = float(((acc + dry) + synth_ch)); the consumed region of
 // the accumulator is zeroed.
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
-                                           const lds_state *stl)
+                                           const lds_state *stl, int boff)
 {
     const int s = blockIdx.x;
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
@@ -1958,8 +2002,8 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
     const double gainVoice = stl ? stl->sp.gainVoice : d.pitch[s].sp.gainVoice;
     const double gainSynth = stl ? stl->sp.gainSynth : d.pitch[s].sp.gainSynth;
     for (int i = threadIdx.x; i < g.N; i += blockDim.x) {
-        int pos = (c.outCounter + i) % g.outSize;
-        int pin = (c.currCounter + i) % g.inSize;
+        int pos = (c.outCounter + boff + i) % g.outSize;
+        int pin = (c.currCounter + boff + i) % g.inSize;
         double v = acc[pos];
         if (dryOn) v += (double)vr[pin] * gainVoice;
         double l = v, r = v;

@@ -77,6 +77,8 @@ def load_library():
     L.vp_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]
     L.vp_kernel_slot_name.argtypes = [C.c_int]
     L.vp_kernel_slot_name.restype = C.c_char_p
+    if hasattr(L, "vp_process_blocks_device"):
+        L.vp_process_blocks_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     if hasattr(L, "vp_set_stream_params"):            # absent only from older builds loaded through VP_AMD_LIB (tools/ab.sh)
         L.vp_set_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vp_get_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -220,6 +222,17 @@ class BatchVocoderProcessor:
             import torch
             stream = torch.cuda.current_stream(d_in.device).cuda_stream
         self._chk(self.L.vp_process_block_device(self.h, d_in.data_ptr(), d_out.data_ptr(), C.c_void_p(stream)))
+
+    def process_blocks_device(self, d_in, d_out, stream=None):
+        """B consecutive blocks at once: torch float32 tensors [B][S][3][N] -> [B][S][2][N]; same results as B calls of
+        process_device (pitch corrector alone: ONE launch, state stays on chip between the blocks)."""
+        assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()
+        B = d_in.shape[0]
+        assert tuple(d_in.shape) == (B, self.n_streams, 3, self.N) and tuple(d_out.shape) == (B, self.n_streams, 2, self.N)
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        self._chk(self.L.vp_process_blocks_device(self.h, d_in.data_ptr(), d_out.data_ptr(), int(B), C.c_void_p(stream)))
 
     def run(self, x):
         """x: float32 numpy [S][3][T], T a multiple of N -> float32 [S][2][T] (block by block)."""
