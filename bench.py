@@ -137,6 +137,9 @@ def main():
                          "configuration; 'exact' (bit-identical to the oracle) is timed beside it as value_exact_mode")
     ap.add_argument("--single-mode", action="store_true",
                     help="do not time the other IIR mode or the STFT kernel (for profiler runs: one kernel population)")
+    ap.add_argument("--yin", default="xcorr", choices=["direct", "xcorr", "fft"],
+                    help="evaluation of the YIN difference function: 'xcorr' (default) is certified to take the same "
+                         "decisions as 'direct' (the reference's arithmetic) and falls back to it otherwise: same output bits")
     ap.add_argument("--blocks-per-step", type=int, default=1,
                     help="host blocks of N samples handed over per step (vp_process_blocks_device; one launch in pitch mode)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -165,6 +168,7 @@ def main():
     S, N, mode = args.streams, args.block, args.mode
     p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"))
     p.prepareToPlay(FS, N, S)
+    p.set_yin_mode(args.yin)
 
     # synthetic inputs in HBM: [U][S][3][N], stream ids unique across ranks
     U = UNIQUE_BLOCKS
@@ -258,7 +262,7 @@ def main():
             "config": {"workload": f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
                                    f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
-                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "frames_per_step": frames_per_step_gpu * n_gpus,
+                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "frames_per_step": frames_per_step_gpu * n_gpus,
                        "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -133,9 +133,16 @@ int vp_get_iir_mode(const vp_handle *h);
  * VP_YIN_DIRECT (default): the reference's O(F tau) sums in its own order; decisions bit-identical.
  * VP_YIN_FFT: Wiener-Khinchin accelerator (one forward + one inverse radix-2 FFT of >= F + tauMax points in
  * LDS).  Values differ by ~1e-13 relative, so a threshold decision CAN differ on a near-tie; the measured
- * rate of frames whose period differs is reported by tests/test_gpu_parity.py. */
+ * rate of frames whose period differs is reported by tests/test_gpu_parity.py.
+ * VP_YIN_XCORR: the difference function as energies minus a cross-correlation (fused multiply-adds: a third of the
+ * arithmetic), CERTIFIED: its values differ from the reference's by at most 2^-39 of the window energy, every
+ * comparison the pitch decision rests on is checked against what that can do to it, and a frame with a comparison
+ * too close to call is recomputed in the reference's arithmetic.  Decisions -- and therefore the output -- are
+ * bit-identical to VP_YIN_DIRECT by construction; only the LPC autocorrelation stays as it is. */
 #define VP_YIN_DIRECT 0
 #define VP_YIN_FFT 1
+#define VP_YIN_XCORR 2
+#define VP_YIN_XCORR_FORCE_FALLBACK 3   /* diagnostic: as XCORR, but every frame is treated as "too close to call" */
 int vp_set_yin_mode(vp_handle *h, int mode);
 int vp_get_yin_mode(const vp_handle *h);
 
@@ -169,8 +176,9 @@ const char *vp_pitch_kernel_name(const vp_handle *h);
  * same meaning as the oracle's counters. Synchronises. */
 int vp_read_ub_counters(vp_handle *h, long out[5]);
 
-/* Diagnostic build (-DVP_STAMPS) only: per-phase timers (100 MHz ticks) of workgroup 0; all zero in
- * the product build. */
+/* Slots 0..61: diagnostic build (-DVP_STAMPS) only, per-phase timers (100 MHz ticks) of workgroup 0, all zero in
+ * the product build.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
+ * certified / handed to the reference's arithmetic. */
 int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
 
 /* Standalone STFT round trip: sqrt-Hann window, batched radix-2 FFT, inverse FFT, overlap-add (frame_len a

@@ -628,3 +628,53 @@ def test_multi_block_launch_equals_block_by_block(iir):
         want = _oracle_run(x, N, dict(vocBool=0))
         got, _, _ = run([B], vocBool=0)
         _assert_equal(got.transpose(1, 2, 0, 3).reshape(S, 2, B * N), want, "multi-block vs oracle")
+
+
+def test_certified_cross_correlation_yin_is_bit_identical():
+    """VP_YIN_XCORR computes the YIN difference function as energies minus a cross-correlation (fused multiply-adds, a
+    third of the arithmetic), certifies every comparison of the pitch decision against a rounding-error bound and falls
+    back to the reference's arithmetic when one is too close to call: the OUTPUT must therefore be bit-identical to
+    VP_YIN_DIRECT (not merely within tolerance), for every signal, and the forced-fallback diagnostic mode as well."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    N, B = 1024, 30
+    x = np.concatenate([_edge_streams(N * B), _streams(10, N * B)], axis=0)
+    S = x.shape[0]
+    outs, states, counts = {}, {}, {}
+    for mode in ("direct", "xcorr", "xcorr_force_fallback"):
+        p = BatchVocoderProcessor()
+        p.prepareToPlay(FS, N, S)
+        p.set_yin_mode(mode)
+        assert p.get_yin_mode() == mode
+        p.yin_certified_counts(reset=True)
+        outs[mode] = p.run(x)
+        counts[mode] = p.yin_certified_counts()                                      # (certified, fallback) frames
+        states[mode] = [p.pitch_state(s_) for s_ in range(S)]
+    for mode in ("xcorr", "xcorr_force_fallback"):
+        _assert_equal(outs[mode], outs["direct"], mode)
+        for s_ in range(S):
+            for k in states["direct"][s_]:
+                assert np.array_equal(states[mode][s_][k], states["direct"][s_][k]), (mode, s_, k)
+    cert, fb = counts["xcorr"]
+    print(f"certified {cert} frames, fell back on {fb} (silence / start-up frames have a zero running sum)")
+    assert counts["direct"] == (0, 0)
+    assert cert > 0 and fb < 0.25 * (cert + fb)
+    assert counts["xcorr_force_fallback"][0] == 0 and counts["xcorr_force_fallback"][1] == cert + fb
+
+
+@pytest.mark.parametrize("seed", [3, 8, 13])
+def test_certified_yin_random_configurations(seed):
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    fs, N, params = _fuzz_case(1000 + seed)
+    S = 3
+    T = max(6, int(26000 * fs / 44100.0) // N) * N
+    x = _streams(S, T, fs=fs)
+    outs = []
+    for mode in ("direct", "xcorr"):
+        p = BatchVocoderProcessor(**params)
+        try:
+            p.prepareToPlay(fs, N, S)
+        except VpError:
+            pytest.skip("geometry exceeds the LDS budget")
+        p.set_yin_mode(mode)
+        outs.append(p.run(x))
+    _assert_equal(outs[1], outs[0], f"seed {seed}: fs={fs} N={N} {params}")

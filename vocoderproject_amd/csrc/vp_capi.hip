@@ -506,6 +506,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     c.iirFast = h->iirMode;
     c.nBlocks = 1;
     c.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
+    c.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
     if (h->spDirty) {
         // orders, key, gains and the dry-path switches travel in each stream's device state (VpPitchState::sp);
         // rewritten here, stream-ordered in front of this block's kernels, whenever a set call changed them
@@ -730,7 +731,7 @@ extern "C" int vp_get_iir_mode(const vp_handle *h) { return h ? h->iirMode : VP_
 
 extern "C" int vp_set_yin_mode(vp_handle *h, int mode)
 {
-    if (!h || (mode != VP_YIN_DIRECT && mode != VP_YIN_FFT)) return VP_ERR_INVALID_ARG;
+    if (!h || mode < VP_YIN_DIRECT || mode > VP_YIN_XCORR_FORCE_FALLBACK) return VP_ERR_INVALID_ARG;
     if (mode == VP_YIN_FFT && h->prepared && h->g.fftLog == 0) return VP_ERR_GEOMETRY;    // work arrays do not fit LDS
     h->yinMode = mode;
     return VP_OK;

@@ -57,6 +57,10 @@ __device__ unsigned long long vp_last_w[16];
 #define STAMP0(D) do { } while (0)
 #endif
 
+#ifndef VP_XC_ACSPLIT
+#define VP_XC_ACSPLIT 13        /* sixteenths of the LPC autocorrelation summed beside the cross-correlation YIN */
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 
@@ -924,6 +928,7 @@ __device__ __forceinline__ int bitrev(int k, int logM) { return (int)(__brev((un
 typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
     lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *htab, *fft;
+    lds_f64 *xcA;      // [1] energy of the YIN window (error bound of the cross-correlation form)
     lds_state *st;
     lds_minidx *part;  // [8]
     int *ishare;       // [4] (generic pointer: used with atomicMin)
@@ -1346,6 +1351,141 @@ __device__ __forceinline__ void pitch_fill_output(const VpGeom &g, const VpCall 
     STAMP(d, 9);
 }
 
+// computeYinTemp's sums (PitchProcess.cpp:350-403) in the reference's own arithmetic, two adjacent lags per lane on
+// waves yw0 .. yw0+wavesY-1, into dY.  (Also the fallback of the cross-correlation form, see yin_pick.)
+__device__ __forceinline__ void yin2_exact_waves(const VpGeom &g, const PitchLds &L, int base, int tid, int yw0, int wavesY, int nPairs)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) d2 lds_d2;
+    if ((tid >> 6) >= yw0 && (tid >> 6) < yw0 + wavesY) {        // whole wavefronts; spare lanes redo the last pair
+                const int ty = tid - yw0 * WAVE;
+                const int l = min(ty, nPairs - 1);
+                const lds_f64 *xa = L.xs + base, *xw = L.xs + base + 2 * l;
+                double accA = 0.0, accB = 0.0;
+                const int F8 = g.F & ~7;
+                double w0 = xw[0], w1 = xw[1];
+                d2 a0[4], v0[4], a1[4], v1[4];
+#define VP_Y2LOAD(A, V, I) _Pragma("unroll") for (int u = 0; u < 4; u++) { A[u] = *(const lds_d2 *)(xa + (I) + 2 * u); V[u] = *(const lds_d2 *)(xw + (I) + 2 + 2 * u); }
+#define VP_Y2COMP(A, V) { const double e_[8] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y, A[3].x, A[3].y}; \
+        const double w_[10] = {w0, w1, V[0].x, V[0].y, V[1].x, V[1].y, V[2].x, V[2].y, V[3].x, V[3].y}; \
+        double dA_[8], dB_[8]; \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { dA_[u] = e_[u] - w_[u]; dB_[u] = e_[u] - w_[u + 1]; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { dA_[u] = dA_[u] * dA_[u]; dB_[u] = dB_[u] * dB_[u]; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { accA += dA_[u]; accB += dB_[u]; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        w0 = w_[8]; w1 = w_[9]; }
+                if (F8 > 0) { VP_Y2LOAD(a0, v0, 0) }
+                for (int i = 0; i < F8; i += 16) {
+                    const bool more1 = i + 8 < F8;
+                    if (more1) { VP_Y2LOAD(a1, v1, i + 8) }
+                    VP_Y2COMP(a0, v0)
+                    if (more1) {
+                        if (i + 16 < F8) { VP_Y2LOAD(a0, v0, i + 16) }
+                        VP_Y2COMP(a1, v1)
+                    }
+                }
+#undef VP_Y2LOAD
+#undef VP_Y2COMP
+                for (int i = F8; i < g.F; i++) {
+                    double dA = xa[i] - xw[i], dB = xa[i] - xw[i + 1];
+                    accA += dA * dA; accB += dB * dB;
+                }
+                if (ty < nPairs) {
+                    L.dY[2 * l] = accA;
+                    if (2 * l + 1 < g.tauMax) L.dY[2 * l + 1] = accB;
+                }
+    }
+}
+
+// The running sum of the difference function (PitchProcess.cpp:395-402) by ONE full wavefront, into cum[].
+__device__ __forceinline__ void yin_cumsum_wave(const VpGeom &g, const PitchLds &L, int tid)
+{
+        // Sixteen entries per trip, ONE read and ONE write for the whole group: lane l holds entry
+        // k0 + (l & 15) (every 16-lane row the same), and the chain is sixteen v_fmac_f64 with a DPP
+        // row-broadcast operand, cap += entry_u * M_u, where lane l's multiplier M_u is 1.0 for u <= (l & 15)
+        // and 0.0 after.  x * 1.0 + cap rounds exactly like cap + x and x * 0.0 + cap is cap (the entries
+        // are finite sums of squares), so lane l ends the trip holding the running sum up to ITS entry --
+        // the same additions in the same order as the serial loop -- and lane 15's value starts the next
+        // trip.  The per-entry form (uniform reads, same-address writes) spent 2.5x the chain's time on
+        // LDS instructions issued from the chain's own wave (tools/ubench_lds.hip).
+        const int lane = tid, l16 = lane & 15;
+        const double one = 1.0, zero = 0.0;
+        double M[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) M[u] = (l16 >= u) ? 1.0 : 0.0;
+        double cap = 0.0;                                                     // running sum before the trip
+        double vnext = (1 + l16 < g.tauMax) ? L.dY[1 + l16] : 0.0;
+        for (int k0 = 1; k0 < g.tauMax; k0 += 16) {
+            const double v = vnext;
+            { const int kn = k0 + 16 + l16; vnext = (kn < g.tauMax) ? L.dY[kn] : 0.0; }
+            VP_FMAC_BCAST(cap, v, M[0], 0);   VP_FMAC_BCAST(cap, v, M[1], 1);   VP_FMAC_BCAST(cap, v, M[2], 2);   VP_FMAC_BCAST(cap, v, M[3], 3);
+            VP_FMAC_BCAST(cap, v, M[4], 4);   VP_FMAC_BCAST(cap, v, M[5], 5);   VP_FMAC_BCAST(cap, v, M[6], 6);   VP_FMAC_BCAST(cap, v, M[7], 7);
+            VP_FMAC_BCAST(cap, v, M[8], 8);   VP_FMAC_BCAST(cap, v, M[9], 9);   VP_FMAC_BCAST(cap, v, M[10], 10); VP_FMAC_BCAST(cap, v, M[11], 11);
+            VP_FMAC_BCAST(cap, v, M[12], 12); VP_FMAC_BCAST(cap, v, M[13], 13); VP_FMAC_BCAST(cap, v, M[14], 14); VP_FMAC_BCAST(cap, v, M[15], 15);
+            if (k0 + l16 < g.tauMax) L.cum[k0 + l16] = cap;
+            double nxt = zero * zero;                                         // +0.0 in a fresh register
+            asm volatile("s_nop 1" : "+v"(cap), "+v"(nxt));                   // VALU write -> DPP read
+            VP_FMAC_BCAST(nxt, cap, one, 15);                                 // lane 15 of the row: the sum so far
+            cap = nxt;
+        }
+        if (lane == 0) { L.dY[0] = 1.0; L.dY[g.tauMax] = 0.0; }               // :395, guard slot (see oracle)
+}
+
+// Normalise, first lag under the tolerance, walk down to the local minimum (PitchProcess.cpp:395-403, 431-440): sets
+// st->pitch / st->period.  cert = 0: dY holds the reference's sums, every comparison is what it is.  cert != 0: dY
+// holds the cross-correlation form's sums, which differ from the reference's by at most
+//     Delta = 2^-39 * (sum of w_j^2 over the F + tauMax samples)          (xcA; derivation in DESIGN.md section 4.1)
+// in absolute value; every comparison the decision rests on is then CERTIFIED -- its two sides must differ by more
+// than the error either side can carry -- and if one is not (or cert == 2, the test hook) the function returns false
+// without touching the state: the caller recomputes the frame in the reference's arithmetic.
+__device__ __forceinline__ bool yin_pick(const VpGeom &g, const VpDev &d, const PitchLds &L, lds_state *st, int tid, int nt, int cert)
+{
+    const double delta = cert ? 1.8189894035458565e-12 * L.xcA[0] : 0.0;    // 2^-39 * window energy
+    for (int k = 1 + tid; k < g.tauMax; k += nt) {
+        const double cm = L.cum[k], q = (double)k / cm, v = L.dY[k] * q;
+        L.dY[k] = v;
+        if (cert) {
+            // |d'~_k - d'_k| <= Delta q (1 + d') + d' (k + 4) u,  q = k / cum_k;  four times that, kept where cum_k was
+            const double dp = fabs(v);
+            double e = 4.0 * (delta * q * (1.0 + dp) + dp * (double)(2 * k + 8) * 1.1102230246251565e-16);
+            if (!(cm > 0.0) || !(e < 1.0)) e = 1e300;                         // silence, or not finite: nothing is certain
+            L.cum[k] = e;
+        }
+    }
+    if (cert && tid == 0) L.cum[g.tauMax] = 0.0;                              // the guard slot dY[tauMax] = 0 is exact
+    __syncthreads();
+    STAMP(d, 13);
+    for (int k = g.tau0 + tid; k < g.tauMax; k += nt) {                    // first tau with d < tol (:431-433)
+        const double v = L.dY[k];
+        if (v < g.yinTol) atomicMin(&L.ishare[0], k);
+        if (cert && !(fabs(v - g.yinTol) > L.cum[k])) L.ishare[1] = 1;       // too close to call
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tau = L.ishare[0];
+        bool sure = !cert || (L.ishare[1] == 0 && cert != 2 && L.xcA[0] > 0.0);
+        if (sure && tau < g.tauMax) {
+            while (true) {                                                   // :435-440
+                const double a = L.dY[tau + 1], b = L.dY[tau];
+                if (cert && !(fabs(a - b) > L.cum[tau + 1] + L.cum[tau])) { sure = false; break; }
+                if (!(a < b)) break;
+                tau += 1;
+                if (tau + 1 >= g.tauMax) break;
+            }
+        }
+        if (sure && tau < g.tauMax) {
+            if (tau >= g.tauMax) atomicAdd(&d.ub[3], 1ULL);
+            st->pitch = g.fs / tau;
+            st->period = tau;
+        }
+        L.ishare[1] = sure ? 0 : 1;
+    }
+    __syncthreads();
+    return L.ishare[1] == 0;
+}
+
 // First half of PitchProcess::processChunkCont (PitchProcess.cpp:253-259): residual of the new samples.
 // Returns true when the chunk has work (analysis marks exist); the caller then runs the shared
 // tail psola -> filterIIR -> fillOutputBuffer (:262-268).
@@ -1380,9 +1520,10 @@ __device__ __forceinline__ bool pitch_can_overlap(const VpGeom &g)
 // coefficients versus xs/yinTemp), and the new frame's buffers are zeroed only afterwards.
 template <bool LITE, bool FAST>
 __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
-                                                     int pS, int s, int pendingCont, bool &hValid)
+                                                     int pS, int s, int pendingCont, bool &hValid, int &xcGenCtr)
 {
     lds_state *st = L.st;
+    const int xcGen = ++xcGenCtr;                     // this Start's value of the prefix-sum flag (ishare[3])
     const int tid = vp_tid(), nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
         if (pendingCont >= 0) {
@@ -1400,11 +1541,17 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         if (st->pitch > 1) { st->prevVoicedPeriod = st->period; st->prevVoicedPitch = st->pitch; }
         st->pitch = 0; st->period = 0;
         L.ishare[0] = INT_MAX;
+        L.ishare[1] = 0;                                                     // "a comparison was too close to call" (yin_pick)
     }
     // LPC ahead of the pitch decisions (see below): needs the time-domain autocorrelation on one wavefront
     const bool specLpc = !c.yinFft && g.orderPitch < WAVE && nt >= 8 * WAVE;
+    // VP_YIN_XCORR: cross-correlation form of the difference function, certified (yin_pick) with the reference's
+    // arithmetic as the fallback; needs the two-lags-per-lane layout on waves 1..4 and a free wave 5
+    const int yNPairs = (g.tauMax + 1) >> 1, yWaves = (yNPairs + WAVE - 1) / WAVE;
+    const int xcCert = (c.yinCert != 0 && !c.yinFft && (g.C & 1) == 0 && yWaves <= 4 && nt == 8 * WAVE) ? c.yinCert : 0;
     const int acM = min(nt - 1 - tid, g.orderPitch);                         // the last wavefront's lag per lane
-    const int acSplit = min((g.F * 15 / 16) & ~15, (g.F - g.orderPitch) & ~15);  // how much of the sum runs beside YIN
+    // how much of the sum runs beside YIN (the cross-correlation form of YIN is shorter: less fits beside it)
+    const int acSplit = min((g.F * (c.yinCert ? VP_XC_ACSPLIT : 15) / 16) & ~15, (g.F - g.orderPitch) & ~15);
     double acSum = 0.0;
     // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
     STAMPW_BEGIN();
@@ -1493,46 +1640,71 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 #ifdef VP_DIAG_NO_YIN
             if (false)
 #endif
-            if ((tid >> 6) >= yw0 && (tid >> 6) < yw0 + wavesY) {        // whole wavefronts; spare lanes redo the last pair
+            const bool xc = xcCert != 0;
+            if (xc && (tid >> 6) == 5) {
+                // cross-correlation form (see below): exclusive prefix sums P[j] of w_j^2 over the F + tauMax samples
+                // the difference function reads, by the otherwise idle wave 5, into eFrame (free until the barrier);
+                // the YIN waves pick them up through the flag when their own sums are done
+                const int nb = g.F + g.tauMax, lane = tid & 63, per = (nb + WAVE - 1) / WAVE, j0 = lane * per;
+                const lds_f64 *w = L.xs + base;
+                lds_f64 *P = L.eF;
+                double loc = 0.0;
+                for (int u = 0; u < per; u++) { const int j = j0 + u; if (j < nb) { const double v = w[j]; loc += v * v; } }
+                double inc = loc;
+                for (int off = 1; off < WAVE; off <<= 1) { const double o = __shfl_up(inc, off, WAVE); if (lane >= off) inc += o; }
+                double run = inc - loc;
+                for (int u = 0; u < per; u++) { const int j = j0 + u; if (j <= nb) { P[j] = run; if (j < nb) { const double v = w[j]; run += v * v; } } }
+                __threadfence_block();
+                if (lane == 0) __hip_atomic_store(&L.ishare[3], xcGen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (xc && (tid >> 6) >= yw0 && (tid >> 6) < yw0 + wavesY) {
+                // d[k] = sum_i w_i^2 + sum_i w_{i+k}^2 - 2 sum_i w_i w_{i+k}: two fused multiply-adds per element and lane
+                // instead of six operations.  NOT the reference's arithmetic (differences ~1e-13 of the window energy).
                 const int ty = tid - yw0 * WAVE;
                 const int l = min(ty, nPairs - 1);
                 const lds_f64 *xa = L.xs + base, *xw = L.xs + base + 2 * l;
                 double accA = 0.0, accB = 0.0;
-                const int F8 = g.F & ~7;
+                // sixteen elements per trip: the wave-uniform factor w_i comes from ONE read (lane l holds w_{i0 + (l & 15)},
+                // every 16-lane row the same) through the DPP row broadcast of v_fmac_f64, the lane's own factors w_{i+k}
+                // stream through registers (aligned ds_read_b128, the next trip's in flight)
+                const int F8 = g.F & ~15, l16 = tid & 15;
                 double w0 = xw[0], w1 = xw[1];
-                d2 a0[4], v0[4], a1[4], v1[4];
-#define VP_Y2LOAD(A, V, I) _Pragma("unroll") for (int u = 0; u < 4; u++) { A[u] = *(const lds_d2 *)(xa + (I) + 2 * u); V[u] = *(const lds_d2 *)(xw + (I) + 2 + 2 * u); }
-#define VP_Y2COMP(A, V) { const double e_[8] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y, A[3].x, A[3].y}; \
-        const double w_[10] = {w0, w1, V[0].x, V[0].y, V[1].x, V[1].y, V[2].x, V[2].y, V[3].x, V[3].y}; \
-        double dA_[8], dB_[8]; \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) { dA_[u] = e_[u] - w_[u]; dB_[u] = e_[u] - w_[u + 1]; } \
-        __builtin_amdgcn_sched_barrier(0); \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) { dA_[u] = dA_[u] * dA_[u]; dB_[u] = dB_[u] * dB_[u]; } \
-        __builtin_amdgcn_sched_barrier(0); \
-        _Pragma("unroll") for (int u = 0; u < 8; u++) { accA += dA_[u]; accB += dB_[u]; } \
-        __builtin_amdgcn_sched_barrier(0); \
-        w0 = w_[8]; w1 = w_[9]; }
-                if (F8 > 0) { VP_Y2LOAD(a0, v0, 0) }
-                for (int i = 0; i < F8; i += 16) {
-                    const bool more1 = i + 8 < F8;
-                    if (more1) { VP_Y2LOAD(a1, v1, i + 8) }
-                    VP_Y2COMP(a0, v0)
+                double E = xa[l16], En = 0.0;
+                d2 v0[8], v1[8];
+#define VP_XLOAD(V, I) _Pragma("unroll") for (int u = 0; u < 8; u++) V[u] = *(const lds_d2 *)(xw + (I) + 2 + 2 * u);
+#define VP_XT(U, WA, WB) VP_FMAC_BCAST(accA, E, WA, U); VP_FMAC_BCAST(accB, E, WB, U);
+#define VP_XCOMP(V) { VP_XT(0, w0, w1) VP_XT(1, w1, V[0].x) VP_XT(2, V[0].x, V[0].y) VP_XT(3, V[0].y, V[1].x) VP_XT(4, V[1].x, V[1].y) \
+        VP_XT(5, V[1].y, V[2].x) VP_XT(6, V[2].x, V[2].y) VP_XT(7, V[2].y, V[3].x) VP_XT(8, V[3].x, V[3].y) VP_XT(9, V[3].y, V[4].x) \
+        VP_XT(10, V[4].x, V[4].y) VP_XT(11, V[4].y, V[5].x) VP_XT(12, V[5].x, V[5].y) VP_XT(13, V[5].y, V[6].x) VP_XT(14, V[6].x, V[6].y) \
+        VP_XT(15, V[6].y, V[7].x) w0 = V[7].x; w1 = V[7].y; }
+                if (F8 > 0) { VP_XLOAD(v0, 0) }
+                for (int i = 0; i < F8; i += 32) {
+                    const bool more1 = i + 16 < F8;
+                    if (more1) { VP_XLOAD(v1, i + 16) En = xa[i + 16 + l16]; }
+                    VP_XCOMP(v0)
                     if (more1) {
-                        if (i + 16 < F8) { VP_Y2LOAD(a0, v0, i + 16) }
-                        VP_Y2COMP(a1, v1)
+                        E = En;
+                        if (i + 32 < F8) { VP_XLOAD(v0, i + 32) En = xa[i + 32 + l16]; }
+                        VP_XCOMP(v1)
+                        E = En;
                     }
                 }
-#undef VP_Y2LOAD
-#undef VP_Y2COMP
-                for (int i = F8; i < g.F; i++) {
-                    double dA = xa[i] - xw[i], dB = xa[i] - xw[i + 1];
-                    accA += dA * dA; accB += dB * dB;
-                }
+#undef VP_XLOAD
+#undef VP_XT
+#undef VP_XCOMP
+                for (int i = F8; i < g.F; i++) { accA = __builtin_fma(xa[i], xw[i], accA); accB = __builtin_fma(xa[i], xw[i + 1], accB); }
+                for (int spin = 0; spin < (1 << 22) &&
+                     __hip_atomic_load(&L.ishare[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xcGen; spin++)
+                    __builtin_amdgcn_s_sleep(1);         // wave 5 finished long ago; bounded so that a bug cannot hang the GPU
+                const lds_f64 *P = L.eF;
+                const double E0 = P[g.F] - P[0];
+                if (ty == 0) L.xcA[0] = P[g.F + g.tauMax];
                 if (ty < nPairs) {
-                    L.dY[2 * l] = accA;
-                    if (2 * l + 1 < g.tauMax) L.dY[2 * l + 1] = accB;
+                    L.dY[2 * l] = E0 + (P[2 * l + g.F] - P[2 * l]) - 2.0 * accA;
+                    if (2 * l + 1 < g.tauMax) L.dY[2 * l + 1] = E0 + (P[2 * l + 1 + g.F] - P[2 * l + 1]) - 2.0 * accB;
                 }
-            }
+            } else
+            if (!xc) yin2_exact_waves(g, L, base, tid, yw0, wavesY, nPairs);
         } else {
 #ifdef VP_DIAG_NO_YIN
         if (false)
@@ -1649,57 +1821,20 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
         STAMPL(27);
     }
-    if (tid < WAVE) {                                                        // :395-402 running sum tmp += yinTemp[k], in order
-        // Sixteen entries per trip, ONE read and ONE write for the whole group: lane l holds entry
-        // k0 + (l & 15) (every 16-lane row the same), and the chain is sixteen v_fmac_f64 with a DPP
-        // row-broadcast operand, cap += entry_u * M_u, where lane l's multiplier M_u is 1.0 for u <= (l & 15)
-        // and 0.0 after.  x * 1.0 + cap rounds exactly like cap + x and x * 0.0 + cap is cap (the entries
-        // are finite sums of squares), so lane l ends the trip holding the running sum up to ITS entry --
-        // the same additions in the same order as the serial loop -- and lane 15's value starts the next
-        // trip.  The per-entry form (uniform reads, same-address writes) spent 2.5x the chain's time on
-        // LDS instructions issued from the chain's own wave (tools/ubench_lds.hip).
-        const int lane = tid, l16 = lane & 15;
-        const double one = 1.0, zero = 0.0;
-        double M[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) M[u] = (l16 >= u) ? 1.0 : 0.0;
-        double cap = 0.0;                                                     // running sum before the trip
-        double vnext = (1 + l16 < g.tauMax) ? L.dY[1 + l16] : 0.0;
-        for (int k0 = 1; k0 < g.tauMax; k0 += 16) {
-            const double v = vnext;
-            { const int kn = k0 + 16 + l16; vnext = (kn < g.tauMax) ? L.dY[kn] : 0.0; }
-            VP_FMAC_BCAST(cap, v, M[0], 0);   VP_FMAC_BCAST(cap, v, M[1], 1);   VP_FMAC_BCAST(cap, v, M[2], 2);   VP_FMAC_BCAST(cap, v, M[3], 3);
-            VP_FMAC_BCAST(cap, v, M[4], 4);   VP_FMAC_BCAST(cap, v, M[5], 5);   VP_FMAC_BCAST(cap, v, M[6], 6);   VP_FMAC_BCAST(cap, v, M[7], 7);
-            VP_FMAC_BCAST(cap, v, M[8], 8);   VP_FMAC_BCAST(cap, v, M[9], 9);   VP_FMAC_BCAST(cap, v, M[10], 10); VP_FMAC_BCAST(cap, v, M[11], 11);
-            VP_FMAC_BCAST(cap, v, M[12], 12); VP_FMAC_BCAST(cap, v, M[13], 13); VP_FMAC_BCAST(cap, v, M[14], 14); VP_FMAC_BCAST(cap, v, M[15], 15);
-            if (k0 + l16 < g.tauMax) L.cum[k0 + l16] = cap;
-            double nxt = zero * zero;                                         // +0.0 in a fresh register
-            asm volatile("s_nop 1" : "+v"(cap), "+v"(nxt));                   // VALU write -> DPP read
-            VP_FMAC_BCAST(nxt, cap, one, 15);                                 // lane 15 of the row: the sum so far
-            cap = nxt;
-        }
-        if (lane == 0) { L.dY[0] = 1.0; L.dY[g.tauMax] = 0.0; }               // :395, guard slot (see oracle)
-    }
+    if (tid < WAVE) yin_cumsum_wave(g, L, tid);                            // :395-402 running sum tmp += yinTemp[k], in order
     __syncthreads();
     STAMP(d, 12);
-    for (int k = 1 + tid; k < g.tauMax; k += nt) L.dY[k] *= (double)k / L.cum[k];
-    __syncthreads();
-    STAMP(d, 13);
-    for (int k = g.tau0 + tid; k < g.tauMax; k += nt)                      // first tau with d < tol (:431-433)
-        if (L.dY[k] < g.yinTol) atomicMin(&L.ishare[0], k);
-    __syncthreads();
-    if (tid == 0) {
-        int tau = L.ishare[0];
-        if (tau < g.tauMax) {
-            while (L.dY[tau + 1] < L.dY[tau]) {                              // :435-440
-                tau += 1;
-                if (tau + 1 >= g.tauMax) break;
-            }
-            if (tau >= g.tauMax) atomicAdd(&d.ub[3], 1ULL);
-            st->pitch = g.fs / tau;
-            st->period = tau;
-        }
-    }
+    if (!yin_pick(g, d, L, st, tid, nt, xcCert)) {
+        // a comparison of the certified form was too close to call (about once in 1e9 frames; always with the
+        // diagnostic mode 3): the frame again, in the reference's arithmetic
+        if (tid == 0) { L.ishare[0] = INT_MAX; L.ishare[1] = 0; atomicAdd(&d.dbg[63], 1ULL); }
+        yin2_exact_waves(g, L, g.toKeep - g.tauMax, tid, 1, yWaves, yNPairs);
+        __syncthreads();
+        if (tid < WAVE) yin_cumsum_wave(g, L, tid);
+        __syncthreads();
+        yin_pick(g, d, L, st, tid, nt, 0);
+    } else if (xcCert && tid == 0)
+        atomicAdd(&d.dbg[62], 1ULL);
     __syncthreads();
     STAMP(d, 2);
     if (tid < WAVE) {                                                        // wave 0, all lanes redundantly (full EXEC)
@@ -1804,6 +1939,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     L.part = (lds_minidx *)(L.htab + (2 * g.tauMax + 2));
     L.st = (lds_state *)(L.part + 8);
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
+    L.xcA = (lds_f64 *)(L.st + 1) + 2;                // behind ishare's 16 bytes, in front of the FFT arrays
     L.fft = (lds_f64 *)(L.st + 1) + 8;                // [2 << fftLog] only when launched with the FFT extension
 
     // Everything the block needs from global memory is requested in ONE go (tracker state, the frame in
@@ -1843,11 +1979,13 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         }
     }
     if (nSteps > 0) load_xs(0, tid);
+    if (tid == 0) L.ishare[3] = 0;                    // prefix-sum flag of the cross-correlation YIN (generation counter)
     __syncthreads();
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
     const bool hValid0 = frameLive0 && (g.C & 63) == 0 && g.orderPitch < WAVE;
 
     bool qValid = false, hValid = hValid0;
+    int xcGenCtr = 0;
     // vp_process_blocks_device: several consecutive blocks in this launch.  The tracker state and the frame in flight
     // stay in LDS between them; per block only the input is ingested (rings, gate), the voice window staged and the
     // output emitted -- exactly what separate launches would do, minus their state round trips.
@@ -1894,7 +2032,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre<LITE, FAST>(g, c, d, L, boff + pS, s, pendingCont, hValid);   // pS: output position only
+                mode = pitch_chunk_start_pre<LITE, FAST>(g, c, d, L, boff + pS, s, pendingCont, hValid, xcGenCtr);   // pS: output position only
                 hValid = (mode != 0) && (g.C & 63) == 0 && g.orderPitch < WAVE;    // computed there for the new coefficients
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period

@@ -171,10 +171,10 @@ class BatchVocoderProcessor:
 
     def set_yin_mode(self, mode):
         """"direct" (default, reference summation order) or "fft" (VP_YIN_FFT accelerator)."""
-        self._chk(self.L.vp_set_yin_mode(self.h, {"direct": 0, "fft": 1}[mode] if isinstance(mode, str) else int(mode)))
+        self._chk(self.L.vp_set_yin_mode(self.h, {"direct": 0, "fft": 1, "xcorr": 2, "xcorr_force_fallback": 3}[mode] if isinstance(mode, str) else int(mode)))
 
     def get_yin_mode(self):
-        return "fft" if self.L.vp_get_yin_mode(self.h) == 1 else "direct"
+        return {0: "direct", 1: "fft", 2: "xcorr", 3: "xcorr_force_fallback"}[self.L.vp_get_yin_mode(self.h)]
 
     def get_iir_mode(self):
         return "fast" if self.L.vp_get_iir_mode(self.h) == 1 else "exact"
@@ -266,6 +266,13 @@ class BatchVocoderProcessor:
         v = (C.c_ulonglong * 64)()
         self._chk(self.L.vp_debug_read_stamps(self.h, v, int(bool(reset))))
         return [t / 100.0 for t in v]
+
+    def yin_certified_counts(self, reset=True):
+        """(frames whose pitch decision the certified cross-correlation form settled, frames it handed to the reference's
+        arithmetic) since the last reset, over all streams; both 0 outside VP_YIN_XCORR."""
+        v = (C.c_ulonglong * 64)()
+        self._chk(self.L.vp_debug_read_stamps(self.h, v, int(bool(reset))))
+        return int(v[62]), int(v[63])
 
     def profile_enable(self, on=True):
         self._chk(self.L.vp_profile_enable(self.h, int(bool(on))))
