@@ -56,12 +56,12 @@ def main():
     print(f"mode={a.mode} S={S} N={N} iir={a.iir}: per-step microseconds of workgroup 0, thread 0's timeline (sum {tot / a.steps:.1f})")
     for i, t in enumerate(st):
         if t and i < 24:
-            print(f"  {PHASES.get(i, i):44s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
+            print(f"  {str(PHASES.get(i, i)):44s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
     if any(st[24:]):
         print("concurrent / nested timers:")
         for i, t in enumerate(st):
-            if t and i >= 24:
-                print(f"  {PHASES.get(i, i):44s} {t / a.steps:9.1f} us")
+            if t and 24 <= i < 62:                       # 62/63 are frame counters of VP_YIN_XCORR, not timers
+                print(f"  {str(PHASES.get(i, i)):44s} {t / a.steps:9.1f} us")
 
 if __name__ == "__main__":
     main()
