@@ -1693,9 +1693,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 #undef VP_XT
 #undef VP_XCOMP
                 for (int i = F8; i < g.F; i++) { accA = __builtin_fma(xa[i], xw[i], accA); accB = __builtin_fma(xa[i], xw[i + 1], accB); }
-                for (int spin = 0; spin < (1 << 22) &&
+                int spin = 0;
+                for (; spin < (1 << 22) &&
                      __hip_atomic_load(&L.ishare[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xcGen; spin++)
                     __builtin_amdgcn_s_sleep(1);         // wave 5 finished long ago; bounded so that a bug cannot hang the GPU
+                if (spin == (1 << 22)) { L.ishare[1] = 1; if ((tid & 63) == 0) atomicAdd(&d.dbg[61], 1ULL); }   // never seen; falls back
                 const lds_f64 *P = L.eF;
                 const double E0 = P[g.F] - P[0];
                 if (ty == 0) L.xcA[0] = P[g.F + g.tauMax];

@@ -272,6 +272,7 @@ class BatchVocoderProcessor:
         arithmetic) since the last reset, over all streams; both 0 outside VP_YIN_XCORR."""
         v = (C.c_ulonglong * 64)()
         self._chk(self.L.vp_debug_read_stamps(self.h, v, int(bool(reset))))
+        assert int(v[61]) == 0, "the prefix-sum flag of VP_YIN_XCORR timed out (kernel bug)"
         return int(v[62]), int(v[63])
 
     def profile_enable(self, on=True):
