@@ -283,6 +283,15 @@ def test_prepare_errors_mirror_reference_asserts():
     with pytest.raises(VpError) as e:
         q.process(np.zeros((1, 3, 16), np.float32))                # processBlock before prepareToPlay
     assert e.value.code == -2
+    # the entry points added on top of the plugin's surface reject nonsense the same way
+    import ctypes as C
+    r = BatchVocoderProcessor()
+    assert r.L.vp_process_blocks_device(r.h, C.c_void_p(16), C.c_void_p(16), 2, None) == -2          # not prepared
+    r.prepareToPlay(FS, 256, 2)
+    assert r.L.vp_process_blocks_device(r.h, C.c_void_p(16), C.c_void_p(16), 0, None) == -1          # VP_ERR_INVALID_ARG
+    assert r.L.vp_process_blocks_device(r.h, None, C.c_void_p(16), 1, None) == -1
+    assert r.L.vp_set_yin_mode(r.h, 7) == -1 and r.L.vp_set_iir_mode(r.h, 5) == -1
+    assert r.L.vp_set_stream_params(r.h, 2, C.byref(r._p)) == -1 and r.L.vp_set_stream_params(r.h, -1, C.byref(r._p)) == -1
 
 
 # ---- full-size properties (BASELINE configs[1] size: 256 streams) ------------------------------------------------------------
