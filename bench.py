@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 FS = 44100.0
 HOP = 256
 ALG_BYTES_PER_FRAME = {"pitch": 3072, "voc": 5120, "both": 5120}
+PROFILE_EVERY = 8       # kernel durations are sampled live inside the timed region (two event records cost the stream 2-3 us)
 # fp64 operations per hop-frame of the reference's arithmetic at the default geometry:
 # the secondary, ALU-side sanity line (no MFMA: nothing on this path is a dense contraction)
 ALG_FLOP_PER_FRAME = {"pitch": 0.51e6, "voc": 0.36e6, "both": 0.87e6}
@@ -192,7 +193,7 @@ def main():
             step(i)
         torch.cuda.synchronize(dev)
         p.profile_read(reset=True)
-        p.profile_enable(True)
+        p.profile_enable(PROFILE_EVERY)       # HIP events around every PROFILE_EVERY-th launch of the timed region
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)

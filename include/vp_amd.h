@@ -160,7 +160,8 @@ int vp_read_pitch_state(vp_handle *h, int stream, vp_pitch_state *out);
 int vp_synchronize(vp_handle *h);
 
 /* Kernel timing with HIP events on the launch stream (bench.py's roofline figures).
- * vp_profile_enable(h, 1) brackets every kernel launch with events; vp_profile_read returns, per
+ * vp_profile_enable(h, k) brackets the kernel launches of every k-th process call with events (k = 1: every call;
+ * the records cost the stream 2-3 us per bracketed launch, so a throughput measurement samples); vp_profile_read returns, per
  * kernel slot, the accumulated milliseconds and launch count since the last reset.
  * Slots: 0 ingest+gate, 1 vocoder, 2 pitch, 3 emit. */
 #define VP_NUM_KERNEL_SLOTS 4

@@ -32,7 +32,9 @@ struct vp_handle {
     hipStream_t ownStream = nullptr;
     int vocWaves = 8;
     size_t vocLds = 0, pitchLds = 0;
-    bool prof = false;
+    int prof = 0;                               // 0 off, k: every k-th launch is bracketed with events
+    unsigned profTick = 0;
+    bool profThis = false;                      // the call in hand is a sampled one
     int iirMode = 0, yinMode = 0;
     // per-stream parameter overrides (vp_set_stream_params): host copy, device copy, upload pending
     std::vector<vp_params> sparams;             // [S] what each stream's treeState holds
@@ -471,14 +473,15 @@ static hipEvent_t get_event(vp_handle *h)
 }
 
 struct ProfScope {
-    vp_handle *h; hipStream_t st; int slot; hipEvent_t a, b;
+    vp_handle *h; hipStream_t st; int slot; hipEvent_t a, b; bool on;
     ProfScope(vp_handle *h_, hipStream_t st_, int slot_) : h(h_), st(st_), slot(slot_)
     {
-        if (h->prof) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
+        on = h->profThis;
+        if (on) { a = get_event(h); b = get_event(h); (void)hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (h->prof) { (void)hipEventRecord(b, st); h->pending.push_back({a, b, slot}); }
+        if (on) { (void)hipEventRecord(b, st); h->pending.push_back({a, b, slot}); }
     }
 };
 
@@ -498,6 +501,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
 {
     const VpGeom &g = h->g;
     const vp_params P = h->params;                                           // snapshot at call entry
+    h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;   // all kernels of every k-th call
     if (P.lpcVoice > VP_ORDER_MAX || P.lpcSynth > VP_ORDER_MAX_SYNTH) return VP_ERR_ORDER;
     VpCall c;
     memset(&c, 0, sizeof c);
@@ -688,7 +692,8 @@ extern "C" int vp_read_ub_counters(vp_handle *h, long out[5])
 extern "C" int vp_profile_enable(vp_handle *h, int on)
 {
     if (!h) return VP_ERR_INVALID_ARG;
-    h->prof = on != 0;
+    h->prof = on < 0 ? 0 : on;
+    h->profTick = 0;
     return VP_OK;
 }
 

@@ -276,7 +276,8 @@ class BatchVocoderProcessor:
         return int(v[62]), int(v[63])
 
     def profile_enable(self, on=True):
-        self._chk(self.L.vp_profile_enable(self.h, int(bool(on))))
+        """True/1: HIP events around every kernel launch; k > 1: around every k-th one; False/0: off."""
+        self._chk(self.L.vp_profile_enable(self.h, int(on)))
 
     def profile_read(self, reset=True):
         ms = (C.c_double * KERNEL_SLOTS)()
