@@ -181,6 +181,8 @@ int vp_read_ub_counters(vp_handle *h, long out[5]);
  * the product build.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
  * certified / handed to the reference's arithmetic. */
 int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
+/* Diagnostic build only: ticks each of the first n streams' workgroups spent inside the pitch kernel (which stream paces a launch). */
+int vp_debug_read_stream_ticks(vp_handle *h, unsigned long long *out, int n, int reset);
 
 /* Standalone STFT round trip: sqrt-Hann window, batched radix-2 FFT, inverse FFT, overlap-add (frame_len a
  * power of two <= 4096, hop dividing it).  NO reference counterpart (the reference contains no FFT, SURVEY.md

@@ -409,7 +409,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.EeArr, (size_t)S * 20));
     RC(dev_alloc(h, &d.hImp, (size_t)S * 64));
     RC(dev_alloc(h, &d.ub, (size_t)5));
-    RC(dev_alloc(h, &d.dbg, (size_t)64));
+    RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S));        // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks
     RC(dev_upload(h, &d.vocWin, vocWin));
     RC(dev_upload(h, &d.pitchStWin, pitchSt));
     RC(dev_upload(h, &d.hannTab, hannTab));
@@ -715,6 +715,19 @@ extern "C" int vp_profile_read(vp_handle *h, double ms[VP_NUM_KERNEL_SLOTS], lon
 }
 
 // Diagnostic (-DVP_STAMPS build only): per-phase 100 MHz ticks accumulated by workgroup 0.
+// Diagnostic build only: accumulated ticks (100 MHz) each stream's workgroup spent inside the pitch kernel.
+extern "C" int vp_debug_read_stream_ticks(vp_handle *h, unsigned long long *out, int n, int reset)
+{
+    if (!h || !out || n < 1) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    n = std::min(n, h->g.S);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->d.dbg + 64, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->d.dbg + 64, 0, (size_t)h->g.S * sizeof(unsigned long long)));
+    return VP_OK;
+}
+
 extern "C" int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset)
 {
     if (!h || !out) return VP_ERR_INVALID_ARG;

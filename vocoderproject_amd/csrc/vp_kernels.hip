@@ -929,6 +929,7 @@ typedef __attribute__((address_space(3))) MinIdx lds_minidx;
 struct PitchLds {
     lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *htab, *fft;
     lds_f64 *xcA;      // [1] energy of the YIN window (error bound of the cross-correlation form)
+    int *lpcFlag;      // generation number of the Start whose LPC coefficients are ready in aPrev
     lds_state *st;
     lds_minidx *part;  // [8]
     int *ishare;       // [4] (generic pointer: used with atomicMin)
@@ -1486,6 +1487,44 @@ __device__ __forceinline__ bool yin_pick(const VpGeom &g, const VpDev &d, const 
     return L.ishare[1] == 0;
 }
 
+// PitchProcess::filterFIR (PitchProcess.cpp:280-302) for FOUR consecutive outputs e[j0 .. j0+3] by one thread:
+// e[j] = a[0] x[j] + sum_{k=1..min(order, j)} x[j-k] a[k], every output summed in the reference's order k = 1, 2, ...
+// The four outputs share the sliding window of inputs (one new x and one coefficient per tap for eight operations,
+// four independent chains) instead of two LDS reads per multiply-add.  x points at the sample of output 0 of the
+// whole filter call (so that j - k >= 0 is the history test), eo at its output.
+__device__ __forceinline__ void fir4(const lds_f64 *x, const lds_f64 *a, int order, int j0, int jEnd, lds_f64 *eo)
+{
+    if (j0 >= jEnd) return;
+    if (j0 >= order && j0 + 4 <= jEnd) {
+        double w0 = x[j0], w1 = x[j0 + 1], w2 = x[j0 + 2], w3 = x[j0 + 3];
+        const double a0 = a[0];
+        double e0 = a0 * w0, e1 = a0 * w1, e2 = a0 * w2, e3 = a0 * w3;
+        int k = 1;
+        for (; k + 3 <= order; k += 4) {                                     // four taps per trip, window registers rotate by name
+            const double ak0 = a[k], ak1 = a[k + 1], ak2 = a[k + 2], ak3 = a[k + 3];
+            const double n0 = x[j0 - k], n1 = x[j0 - k - 1], n2 = x[j0 - k - 2], n3 = x[j0 - k - 3];
+            e0 += n0 * ak0; e1 += w0 * ak0; e2 += w1 * ak0; e3 += w2 * ak0;   // tap k:   x[j-k] for j = j0..j0+3
+            e0 += n1 * ak1; e1 += n0 * ak1; e2 += w0 * ak1; e3 += w1 * ak1;   // tap k+1
+            e0 += n2 * ak2; e1 += n1 * ak2; e2 += n0 * ak2; e3 += w0 * ak2;   // tap k+2
+            e0 += n3 * ak3; e1 += n2 * ak3; e2 += n1 * ak3; e3 += n0 * ak3;   // tap k+3
+            w3 = n0; w2 = n1; w1 = n2; w0 = n3;                               // the window is now x[j0-k-3 .. j0-k]
+        }
+        for (; k <= order; k++) {
+            const double ak = a[k], n0 = x[j0 - k];
+            e0 += n0 * ak; e1 += w0 * ak; e2 += w1 * ak; e3 += w2 * ak;
+            w3 = w2; w2 = w1; w1 = w0; w0 = n0;
+        }
+        eo[j0] = e0; eo[j0 + 1] = e1; eo[j0 + 2] = e2; eo[j0 + 3] = e3;
+        return;
+    }
+    for (int j = j0; j < min(j0 + 4, jEnd); j++) {                           // the filter's first outputs (short history) and ragged ends
+        double e = a[0] * x[j];
+        const int kmax = min(order, j);
+        for (int k = 1; k <= kmax; k++) e += x[j - k] * a[k];
+        eo[j] = e;
+    }
+}
+
 // First half of PitchProcess::processChunkCont (PitchProcess.cpp:253-259): residual of the new samples.
 // Returns true when the chunk has work (analysis marks exist); the caller then runs the shared
 // tail psola -> filterIIR -> fillOutputBuffer (:262-268).
@@ -1549,6 +1588,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     // arithmetic as the fallback; needs the two-lags-per-lane layout on waves 1..4 and a free wave 5
     const int yNPairs = (g.tauMax + 1) >> 1, yWaves = (yNPairs + WAVE - 1) / WAVE;
     const int xcCert = (c.yinCert != 0 && !c.yinFft && (g.C & 1) == 0 && yWaves <= 4 && nt == 8 * WAVE) ? c.yinCert : 0;
+    const bool levLate = xcCert != 0;                 // Levinson-Durbin at the top of the marks phase instead of beside the running sum
     const int acM = min(nt - 1 - tid, g.orderPitch);                         // the last wavefront's lag per lane
     // how much of the sum runs beside YIN (the cross-correlation form of YIN is shorter: less fits beside it)
     const int acSplit = min((g.F * (c.yinCert ? VP_XC_ACSPLIT : 15) / 16) & ~15, (g.F - g.orderPitch) & ~15);
@@ -1817,11 +1857,17 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         for (int n = nU; n < g.F - acM; n++) acSum += x[n] * xm[n];
         L.r[acM] = acSum / (double)g.F;                                       // spare lanes: identical stores
         STAMPL(26);
-        const int order = g.orderPitch;
-        const bool z = (order < 16) ? levinson_row16(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
-                                    : levinson_wave(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
-        if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
-        STAMPL(27);
+        // Levinson-Durbin: here, beside wave 0's running sum, when YIN runs in the reference's arithmetic (this
+        // wavefront then has only a sixteenth of the autocorrelation left to do in this phase); with the
+        // cross-correlation YIN more of the autocorrelation lands here and the recursion would pace the phase, so it
+        // follows at the top of the marks phase instead (levLate)
+        if (!levLate) {
+            const int order = g.orderPitch;
+            const bool z = (order < 16) ? levinson_row16(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
+                                        : levinson_wave(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
+            if (tid == nt - 1) { L.ishare[2] = z ? 1 : 0; *L.lpcFlag = xcGen; }   // (a barrier follows before the FIR waves look)
+            STAMPL(27);
+        }
     }
     if (tid < WAVE) yin_cumsum_wave(g, L, tid);                            // :395-402 running sum tmp += yinTemp[k], in order
     __syncthreads();
@@ -1852,19 +1898,26 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             const int rank = (nw < 8 || wv < 4) ? wv - 1 : wv - 2, nWork = (nw < 8) ? nw - 2 : nw - 3;
             const int order = g.orderPitch;
             const lds_f64 *a = L.aPrev;
-            for (int j = rank * WAVE + (tid & 63); j < g.toKeep + g.F; j += nWork * WAVE) {
-                double e = a[0] * L.xs[j];
-                int kmax = min(order, j);
-                for (int k = 1; k <= kmax; k++) e += L.xs[j - k] * a[k];
-                L.eF[j] = e;
-            }
+            // the coefficients come from the last wavefront, a few microseconds into this phase (flag = this Start's
+            // generation number; bounded wait so that a bug cannot hang the GPU -- a timeout is counted and would show
+            // as a parity failure, never as a hang)
+            int spin = 0;
+            for (; spin < (1 << 22) && __hip_atomic_load(L.lpcFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xcGen; spin++)
+                __builtin_amdgcn_s_sleep(1);
+            if (spin == (1 << 22) && (tid & 63) == 0) atomicAdd(&d.dbg[61], 1ULL);
+            for (int j = 4 * (rank * WAVE + (tid & 63)); j < g.toKeep + g.F; j += 4 * nWork * WAVE)
+                fir4((const lds_f64 *)L.xs, a, order, j, g.toKeep + g.F, L.eF);
         }
     } else if (tid >= nt - WAVE && g.orderPitch < WAVE) {
         // meanwhile, on the last wavefront (FFT mode: Levinson-Durbin first, the autocorrelation came late) ...
-        if (!specLpc) {
+        if (!specLpc || levLate) {
+            STAMPL_BEGIN();
             const bool z = (g.orderPitch < 16) ? levinson_row16(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps)
                                                : levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);
             if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
+            __threadfence_block();
+            if (tid == nt - 1) __hip_atomic_store(L.lpcFlag, xcGen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the FIR waves may go
+            STAMPL(27);
         }
         if ((g.C & 63) == 0) {
             // ... the impulse response of the new 1/A(z) for the block-form IIR (cum[] is dead after
@@ -1916,6 +1969,9 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                                                   float *__restrict__ out0, double *smem)
 {
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+#ifdef VP_STAMPS
+    const unsigned long long wgT0 = wall_clock64();
+#endif
     // the block in hand (vp_process_blocks_device runs several per launch): its offset in samples from the first one
     // -- the ring and output counters of `c` describe the first block, later ones are that much further on --, its
     // chunk-step count and its I/O slabs
@@ -1942,6 +1998,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     L.st = (lds_state *)(L.part + 8);
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
     L.xcA = (lds_f64 *)(L.st + 1) + 2;                // behind ishare's 16 bytes, in front of the FFT arrays
+    L.lpcFlag = (int *)((char *)smem + ((size_t)((lds_i32 *)((lds_f64 *)(L.st + 1) + 3) - (lds_i32 *)smem)) * sizeof(int));
     L.fft = (lds_f64 *)(L.st + 1) + 8;                // [2 << fftLog] only when launched with the FFT extension
 
     // Everything the block needs from global memory is requested in ONE go (tracker state, the frame in
@@ -1981,7 +2038,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         }
     }
     if (nSteps > 0) load_xs(0, tid);
-    if (tid == 0) L.ishare[3] = 0;                    // prefix-sum flag of the cross-correlation YIN (generation counter)
+    if (tid == 0) { L.ishare[3] = 0; *L.lpcFlag = 0; }   // flags (generation counters): YIN prefix sums, LPC coefficients
     __syncthreads();
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
     const bool hValid0 = frameLive0 && (g.C & 63) == 0 && g.orderPitch < WAVE;
@@ -2073,6 +2130,9 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         __syncthreads();
         emit_block(g, c, d, out, L.st, boff);
     }
+#ifdef VP_STAMPS
+    if (tid == 0) d.dbg[64 + s] += wall_clock64() - wgT0;
+#endif
 }
 
 // Four builds of the one body: the IIR mode is a compile-time choice so that the exact recursion's big
