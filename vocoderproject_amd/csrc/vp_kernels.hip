@@ -58,7 +58,7 @@ __device__ unsigned long long vp_last_w[16];
 #endif
 
 #ifndef VP_XC_ACSPLIT
-#define VP_XC_ACSPLIT 13        /* sixteenths of the LPC autocorrelation summed beside the cross-correlation YIN */
+#define VP_XC_ACSPLIT 11        /* sixteenths of the LPC autocorrelation summed beside the cross-correlation YIN */
 #endif
 
 // ------------------------------------------------------------------------------------------------
