@@ -1529,18 +1529,19 @@ __device__ __forceinline__ void fir4(const lds_f64 *x, const lds_f64 *a, int ord
 // Returns true when the chunk has work (analysis marks exist); the caller then runs the shared
 // tail psola -> filterIIR -> fillOutputBuffer (:262-268).
 __device__ __forceinline__ bool pitch_chunk_cont_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
-                                                     int nChunk, int pS, int s)
+                                                     int nChunk, int pS, int s, bool noBarrier)
 {
     if (L.st->nAn == 0) return false;
-    const int order = g.orderPitch;
-    const lds_f64 *a = L.st->a;
-    for (int i = vp_tid(); i < g.C; i += blockDim.x) {                   // filterFIR(F-C, C, toKeep+F+(n-1)C)
-        int xi = g.toKeep + g.F - g.C + i;
-        double e = a[0] * L.xs[xi];
-        for (int k = 1; k <= order; k++) e += L.xs[xi - k] * a[k];
-        L.eF[g.toKeep + g.F + (nChunk - 1) * g.C + i] = e;
+    // filterFIR(F-C, C, toKeep+F+(n-1)C): C new residual samples, four per thread (fir4), by wave 1 -- wave 0 goes
+    // straight on to PSOLA's grain table when `noBarrier` (nothing there reads the residual; the barrier behind the
+    // table is the one the second pass needs anyway)
+    const int tid = vp_tid(), w1 = (blockDim.x >= 2 * WAVE) ? WAVE : 0;
+    if (tid >= w1 && tid < w1 + WAVE) {
+        const int x0 = g.toKeep + g.F - g.C;                               // first input sample of the chunk; full history left of it
+        for (int j = x0 + 4 * (tid - w1); j < g.toKeep + g.F; j += 4 * WAVE)
+            fir4((const lds_f64 *)L.xs, (const lds_f64 *)L.st->a, g.orderPitch, j, g.toKeep + g.F, L.eF + nChunk * g.C);
     }
-    __syncthreads();
+    if (!noBarrier) __syncthreads();
     STAMP(d, 10);
     return true;
 }
@@ -2079,7 +2080,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
             if (sub == 0) {
                 if (nChunk == 0) continue;
                 nC = nChunk;
-                mode = pitch_chunk_cont_pre(g, c, d, L, nChunk, pS, s) ? 2 : 0;
+                mode = pitch_chunk_cont_pre(g, c, d, L, nChunk, pS, s, qValid) ? 2 : 0;   // qValid: PSOLA starts with the grain table
                 if (mode == 2 && nChunk == g.cpf - 1) {
                     // a new frame starts in this step: leave this chunk's IIR + output to wave 0 during
                     // the new frame's YIN phase (pitch_chunk_start_pre)
