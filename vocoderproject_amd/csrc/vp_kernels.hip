@@ -930,6 +930,7 @@ struct PitchLds {
     lds_f64 *xs, *eF, *oE, *yF, *dY, *cum, *r, *aPrev, *qtab, *htab, *fft;
     lds_f64 *xcA;      // [1] energy of the YIN window (error bound of the cross-correlation form)
     int *lpcFlag;      // generation number of the Start whose LPC coefficients are ready in aPrev
+    int *psFlag;       // generation number of the grain table built ahead of its chunk (pitch_iir)
     lds_state *st;
     lds_minidx *part;  // [8]
     int *ishare;       // [4] (generic pointer: used with atomicMin)
@@ -1180,72 +1181,77 @@ struct GrainTab {                       // lives in the yinTemp/cum scratch, fre
     lds_i32 *stMark, *srcBase, *flags, *startIdx, *stopIdx;   // [VP_MARKS]
 };
 
-__device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS, bool &qValid)
+__device__ __forceinline__ GrainTab psola_grain_tab(const PitchLds &L)
 {
-    lds_state *st = L.st;
-    const int tid = vp_tid(), nt = blockDim.x;
-    const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
-    const int nG = 2 * T + 1;
-    const lds_f64 *hw = L.htab;                       // d.hannTab + d.hannOff[T], staged below
-    const double beta = st->beta;
-    const int nSt = st->nSt;
     GrainTab G;
     G.x0 = L.dY; G.xN = L.dY + VP_MARKS;
     G.stMark = (lds_i32 *)(L.dY + 2 * VP_MARKS); G.srcBase = G.stMark + VP_MARKS; G.flags = G.srcBase + VP_MARKS;
     G.startIdx = G.flags + VP_MARKS; G.stopIdx = G.startIdx + VP_MARKS;
-    // xInterp[j] - stMark = (j - T)/beta is the same for every grain of the frame (:700,715,731):
-    // the 2T+1 quotients are computed once per frame, x[j] is then one exact add away.
-    if (!qValid) {                                    // once per frame and kernel launch; later chunks come here behind a barrier
-        const double *hg = d.hannTab + d.hannOff[T];
-        for (int j = tid; j < nG; j += nt) { L.qtab[j] = (double)(j - T) / beta; L.htab[j] = hg[j]; }
-        qValid = true;
-        __syncthreads();
-    }
-    if (tid < WAVE) {
-        // one lane per synthesis mark: the marks ascend, so the marks that are due in this chunk
-        // (:685 stMark - T < (nChunk+1) C) form a prefix of the pending ones; each lane prepares
-        // its own grain entry (closest analysis mark :692-694, x-range, output range).
-        const int smi0 = st->stMarkIdx;
-        const int smi = smi0 + tid;
-        const bool have = smi < nSt;
-        const int stMark = have ? st->stMarks[smi] : 0;
-        const bool due = have && !(stMark - T >= (nChunk + 1) * g.C);
-        const unsigned long long dueMask = __ballot(due);
-        const unsigned long long notDue = ~dueMask;
-        const int ng = notDue ? (int)__builtin_ctzll(notDue) : 64;          // length of the due prefix
-        if (tid < ng) {
-            bool q2 = false;
-            int clIdx = closest_an_mark_idx(g, st, stMark, T, nChunk, pS, q2);
-            if (q2) atomicAdd(&d.ub[0], 1ULL);
-            int clAnMark;
-            if (clIdx >= 0)
-                clAnMark = st->anMarks[clIdx];
-            else {                                                           // Q3
-                int j = st->nPrevAn - clIdx;
-                atomicAdd(&d.ub[1], 1ULL);
-                clAnMark = (j >= 0 && j < VP_MARKS) ? st->prevAnMarks[j] : 0;
-            }
-            const double dSt = (double)stMark;
-            const double x0 = dSt + L.qtab[0];                              // xInterp[0]
-            const double xN = dSt + L.qtab[nG - 1];                         // xInterp.back()
-            G.x0[tid] = x0; G.xN[tid] = xN;
-            G.stMark[tid] = stMark;
-            G.srcBase[tid] = g.toKeep + clAnMark - T;
-            G.flags[tid] = (smi == 0 ? 1 : 0) | (smi == nSt - 1 ? 2 : 0);
-            G.startIdx[tid] = max((int)floor(x0), 0);
-            G.stopIdx[tid] = min((int)ceil(xN), g.F);
+    return G;
+}
+
+// Pass 1 of a chunk's PSOLA, by ONE full wavefront (lane = tid & 63): one lane per synthesis mark.  The marks ascend,
+// so the marks that are due in this chunk (:685 stMark - T < (nChunk+1) C) form a prefix of the pending ones; each
+// lane prepares its own grain entry (closest analysis mark :692-694, x-range, output range).  Leaves the number of
+// grains in ishare[1] and advances st->stMarkIdx.
+__device__ __forceinline__ void psola_table_wave(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS)
+{
+    lds_state *st = L.st;
+    const int lane = vp_tid() & 63;
+    const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
+    const int nG = 2 * T + 1;
+    const int nSt = st->nSt;
+    const GrainTab G = psola_grain_tab(L);
+    const int smi0 = st->stMarkIdx;
+    const int smi = smi0 + lane;
+    const bool have = smi < nSt;
+    const int stMark = have ? st->stMarks[smi] : 0;
+    const bool due = have && !(stMark - T >= (nChunk + 1) * g.C);
+    const unsigned long long dueMask = __ballot(due);
+    const unsigned long long notDue = ~dueMask;
+    const int ng = notDue ? (int)__builtin_ctzll(notDue) : 64;          // length of the due prefix
+    if (lane < ng) {
+        bool q2 = false;
+        int clIdx = closest_an_mark_idx(g, st, stMark, T, nChunk, pS, q2);
+        if (q2) atomicAdd(&d.ub[0], 1ULL);
+        int clAnMark;
+        if (clIdx >= 0)
+            clAnMark = st->anMarks[clIdx];
+        else {                                                           // Q3
+            int j = st->nPrevAn - clIdx;
+            atomicAdd(&d.ub[1], 1ULL);
+            clAnMark = (j >= 0 && j < VP_MARKS) ? st->prevAnMarks[j] : 0;
         }
-        const int smiNew = smi0 + ng;
-        if (tid == 0) { st->stMarkIdx = smiNew; L.ishare[1] = ng; }
+        const double dSt = (double)stMark;
+        const double x0 = dSt + L.qtab[0];                              // xInterp[0]
+        const double xN = dSt + L.qtab[nG - 1];                         // xInterp.back()
+        G.x0[lane] = x0; G.xN[lane] = xN;
+        G.stMark[lane] = stMark;
+        G.srcBase[lane] = g.toKeep + clAnMark - T;
+        G.flags[lane] = (smi == 0 ? 1 : 0) | (smi == nSt - 1 ? 2 : 0);
+        G.startIdx[lane] = max((int)floor(x0), 0);
+        G.stopIdx[lane] = min((int)ceil(xN), g.F);
     }
-    __syncthreads();
-    STAMP(d, 14);
+    if (lane == 0) { st->stMarkIdx = smi0 + ng; L.ishare[1] = ng; }
+}
+
+// Pass 2: every output sample adds the grains that cover it, in grain order; thread `tix` of `nthr`.  Samples below
+// `loMin` are skipped: with loMin = nChunk C those are outEFrame entries of chunks that have already been filtered and
+// sent out, which nothing reads again (filterIIR :307-322 takes [nChunk C, (nChunk+1) C)), see Q5 in SURVEY.md.
+__device__ __forceinline__ void psola_pass2(const VpGeom &g, const PitchLds &L, int tix, int nthr, int loMin)
+{
+    lds_state *st = L.st;
+    const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
+    const int nG = 2 * T + 1;
+    const lds_f64 *hw = L.htab;                       // d.hannTab + d.hannOff[T], staged by psola()
+    const double beta = st->beta;
+    const GrainTab G = psola_grain_tab(L);
     const int ng = L.ishare[1];
     if (ng > 0) {
-        const int lo = G.startIdx[0];                                       // marks ascend: first grain starts first
+        const int lo = max(G.startIdx[0], loMin);                           // marks ascend: first grain starts first
         int hi = 0;
         for (int q = 0; q < ng; q++) hi = max(hi, G.stopIdx[q]);
-        for (int i = lo + tid; i < hi; i += nt) {
+        for (int i = lo + tix; i < hi; i += nthr) {
             const double di = (double)i;
             double accv = L.oE[i];
             for (int q = 0; q < ng; q++) {
@@ -1280,8 +1286,77 @@ __device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const Pit
             L.oE[i] = accv;
         }
     }
+}
+
+__device__ __forceinline__ void psola(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, int pS, bool &qValid)
+{
+    lds_state *st = L.st;
+    const int tid = vp_tid(), nt = blockDim.x;
+    // xInterp[j] - stMark = (j - T)/beta is the same for every grain of the frame (:700,715,731):
+    // the 2T+1 quotients are computed once per frame, x[j] is then one exact add away.
+    if (!qValid) {                                    // once per frame and kernel launch; later chunks come here behind a barrier
+        const int T = (st->pitch > 1) ? st->period : st->prevVoicedPeriod;
+        const int nG = 2 * T + 1;
+        const double beta = st->beta;
+        const double *hg = d.hannTab + d.hannOff[T];
+        for (int j = tid; j < nG; j += nt) { L.qtab[j] = (double)(j - T) / beta; L.htab[j] = hg[j]; }
+        qValid = true;
+        __syncthreads();
+    }
+    if (tid < WAVE) psola_table_wave(g, d, L, nChunk, pS);
+    __syncthreads();
+    STAMP(d, 14);
+    psola_pass2(g, L, tid, nt, 0);
     __syncthreads();
     STAMP(d, 7);
+}
+
+// PitchProcess::filterFIR (PitchProcess.cpp:280-302) for FOUR consecutive outputs e[j0 .. j0+3] by one thread:
+// e[j] = a[0] x[j] + sum_{k=1..min(order, j)} x[j-k] a[k], every output summed in the reference's order k = 1, 2, ...
+// The four outputs share the sliding window of inputs (one new x and one coefficient per tap for eight operations,
+// four independent chains) instead of two LDS reads per multiply-add.  x points at the sample of output 0 of the
+// whole filter call (so that j - k >= 0 is the history test), eo at its output.
+__device__ __forceinline__ void fir4(const lds_f64 *x, const lds_f64 *a, int order, int j0, int jEnd, lds_f64 *eo)
+{
+    if (j0 >= jEnd) return;
+    if (j0 >= order && j0 + 4 <= jEnd) {
+        double w0 = x[j0], w1 = x[j0 + 1], w2 = x[j0 + 2], w3 = x[j0 + 3];
+        const double a0 = a[0];
+        double e0 = a0 * w0, e1 = a0 * w1, e2 = a0 * w2, e3 = a0 * w3;
+        int k = 1;
+        for (; k + 3 <= order; k += 4) {                                     // four taps per trip, window registers rotate by name
+            const double ak0 = a[k], ak1 = a[k + 1], ak2 = a[k + 2], ak3 = a[k + 3];
+            const double n0 = x[j0 - k], n1 = x[j0 - k - 1], n2 = x[j0 - k - 2], n3 = x[j0 - k - 3];
+            e0 += n0 * ak0; e1 += w0 * ak0; e2 += w1 * ak0; e3 += w2 * ak0;   // tap k:   x[j-k] for j = j0..j0+3
+            e0 += n1 * ak1; e1 += n0 * ak1; e2 += w0 * ak1; e3 += w1 * ak1;   // tap k+1
+            e0 += n2 * ak2; e1 += n1 * ak2; e2 += n0 * ak2; e3 += w0 * ak2;   // tap k+2
+            e0 += n3 * ak3; e1 += n2 * ak3; e2 += n1 * ak3; e3 += n0 * ak3;   // tap k+3
+            w3 = n0; w2 = n1; w1 = n2; w0 = n3;                               // the window is now x[j0-k-3 .. j0-k]
+        }
+        for (; k <= order; k++) {
+            const double ak = a[k], n0 = x[j0 - k];
+            e0 += n0 * ak; e1 += w0 * ak; e2 += w1 * ak; e3 += w2 * ak;
+            w3 = w2; w2 = w1; w1 = w0; w0 = n0;
+        }
+        eo[j0] = e0; eo[j0 + 1] = e1; eo[j0 + 2] = e2; eo[j0 + 3] = e3;
+        return;
+    }
+    for (int j = j0; j < min(j0 + 4, jEnd); j++) {                           // the filter's first outputs (short history) and ragged ends
+        double e = a[0] * x[j];
+        const int kmax = min(order, j);
+        for (int k = 1; k <= kmax; k++) e += x[j - k] * a[k];
+        eo[j] = e;
+    }
+}
+
+// filterFIR(F-C, C, toKeep+F+(n-1)C) :253-259 -- the C new residual samples of chunk nChunk, four per thread (fir4), by ONE
+// wavefront; xsStep = the voice window of the step that chunk belongs to
+__device__ __forceinline__ void fir_cont_wave(const VpGeom &g, const PitchLds &L, const lds_f64 *xsStep, int nChunk)
+{
+    const int lane = vp_tid() & 63;
+    const int x0 = g.toKeep + g.F - g.C;                                   // first input sample of the chunk; full history left of it
+    for (int j = x0 + 4 * lane; j < g.toKeep + g.F; j += 4 * WAVE)
+        fir4(xsStep, (const lds_f64 *)L.st->a, g.orderPitch, j, g.toKeep + g.F, L.eF + nChunk * g.C);
 }
 
 // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
@@ -1319,9 +1394,32 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
 }
 
 template <bool LITE, bool FAST>
-__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool &hValid)
+// The chunk's IIR on wave 0.  `ahead`: the frame's NEXT chunk belongs to the next step of this block and its voice
+// window (xsNext) is staged, so the other wavefronts do that chunk's residual FIR, grain table (wave 1, which then raises
+// a flag) and second PSOLA pass now instead of waiting: none of it touches what the recursion reads or writes (the
+// second pass skips the outEFrame entries below its own chunk, which are dead anyway, see psola_pass2).
+__device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const PitchLds &L, int nChunk, bool &hValid, bool ahead,
+                                          const lds_f64 *xsNext, int pSNext, int &psGen)
 {
-    if (vp_tid() < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
+    const int tid = vp_tid(), nt = blockDim.x;
+    const int gen = ahead ? ++psGen : 0;
+    if (tid < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
+    else if (ahead) {
+        if (tid < 2 * WAVE) {
+            fir_cont_wave(g, L, xsNext, nChunk + 1);
+            psola_table_wave(g, d, L, nChunk + 1, pSNext);
+            __threadfence_block();
+            if (tid == WAVE) __hip_atomic_store(L.psFlag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        int spin = 0;                                  // bounded: a bug shows as a parity failure and a count, never as a hang
+        for (; spin < (1 << 22) && __hip_atomic_load(L.psFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen; spin++)
+            __builtin_amdgcn_s_sleep(1);
+        if (spin == (1 << 22) && (tid & 63) == 0) atomicAdd(&d.dbg[61], 1ULL);
+        // (wave 4 shares wave 0's SIMD and stays out of the recursion's way)
+        const int wv = tid >> 6, nw = nt >> 6;
+        if (nw != 8) psola_pass2(g, L, tid - WAVE, nt - WAVE, (nChunk + 1) * g.C);
+        else if (wv != 4) psola_pass2(g, L, (wv < 4 ? wv - 1 : wv - 2) * WAVE + (tid & 63), 6 * WAVE, (nChunk + 1) * g.C);
+    }
     __syncthreads();
     STAMP(d, 8);
 }
@@ -1487,44 +1585,6 @@ __device__ __forceinline__ bool yin_pick(const VpGeom &g, const VpDev &d, const 
     return L.ishare[1] == 0;
 }
 
-// PitchProcess::filterFIR (PitchProcess.cpp:280-302) for FOUR consecutive outputs e[j0 .. j0+3] by one thread:
-// e[j] = a[0] x[j] + sum_{k=1..min(order, j)} x[j-k] a[k], every output summed in the reference's order k = 1, 2, ...
-// The four outputs share the sliding window of inputs (one new x and one coefficient per tap for eight operations,
-// four independent chains) instead of two LDS reads per multiply-add.  x points at the sample of output 0 of the
-// whole filter call (so that j - k >= 0 is the history test), eo at its output.
-__device__ __forceinline__ void fir4(const lds_f64 *x, const lds_f64 *a, int order, int j0, int jEnd, lds_f64 *eo)
-{
-    if (j0 >= jEnd) return;
-    if (j0 >= order && j0 + 4 <= jEnd) {
-        double w0 = x[j0], w1 = x[j0 + 1], w2 = x[j0 + 2], w3 = x[j0 + 3];
-        const double a0 = a[0];
-        double e0 = a0 * w0, e1 = a0 * w1, e2 = a0 * w2, e3 = a0 * w3;
-        int k = 1;
-        for (; k + 3 <= order; k += 4) {                                     // four taps per trip, window registers rotate by name
-            const double ak0 = a[k], ak1 = a[k + 1], ak2 = a[k + 2], ak3 = a[k + 3];
-            const double n0 = x[j0 - k], n1 = x[j0 - k - 1], n2 = x[j0 - k - 2], n3 = x[j0 - k - 3];
-            e0 += n0 * ak0; e1 += w0 * ak0; e2 += w1 * ak0; e3 += w2 * ak0;   // tap k:   x[j-k] for j = j0..j0+3
-            e0 += n1 * ak1; e1 += n0 * ak1; e2 += w0 * ak1; e3 += w1 * ak1;   // tap k+1
-            e0 += n2 * ak2; e1 += n1 * ak2; e2 += n0 * ak2; e3 += w0 * ak2;   // tap k+2
-            e0 += n3 * ak3; e1 += n2 * ak3; e2 += n1 * ak3; e3 += n0 * ak3;   // tap k+3
-            w3 = n0; w2 = n1; w1 = n2; w0 = n3;                               // the window is now x[j0-k-3 .. j0-k]
-        }
-        for (; k <= order; k++) {
-            const double ak = a[k], n0 = x[j0 - k];
-            e0 += n0 * ak; e1 += w0 * ak; e2 += w1 * ak; e3 += w2 * ak;
-            w3 = w2; w2 = w1; w1 = w0; w0 = n0;
-        }
-        eo[j0] = e0; eo[j0 + 1] = e1; eo[j0 + 2] = e2; eo[j0 + 3] = e3;
-        return;
-    }
-    for (int j = j0; j < min(j0 + 4, jEnd); j++) {                           // the filter's first outputs (short history) and ragged ends
-        double e = a[0] * x[j];
-        const int kmax = min(order, j);
-        for (int k = 1; k <= kmax; k++) e += x[j - k] * a[k];
-        eo[j] = e;
-    }
-}
-
 // First half of PitchProcess::processChunkCont (PitchProcess.cpp:253-259): residual of the new samples.
 // Returns true when the chunk has work (analysis marks exist); the caller then runs the shared
 // tail psola -> filterIIR -> fillOutputBuffer (:262-268).
@@ -1532,15 +1592,10 @@ __device__ __forceinline__ bool pitch_chunk_cont_pre(const VpGeom &g, const VpCa
                                                      int nChunk, int pS, int s, bool noBarrier)
 {
     if (L.st->nAn == 0) return false;
-    // filterFIR(F-C, C, toKeep+F+(n-1)C): C new residual samples, four per thread (fir4), by wave 1 -- wave 0 goes
-    // straight on to PSOLA's grain table when `noBarrier` (nothing there reads the residual; the barrier behind the
-    // table is the one the second pass needs anyway)
+    // by wave 1 -- wave 0 goes straight on to PSOLA's grain table when `noBarrier` (nothing there reads the residual;
+    // the barrier behind the table is the one the second pass needs anyway)
     const int tid = vp_tid(), w1 = (blockDim.x >= 2 * WAVE) ? WAVE : 0;
-    if (tid >= w1 && tid < w1 + WAVE) {
-        const int x0 = g.toKeep + g.F - g.C;                               // first input sample of the chunk; full history left of it
-        for (int j = x0 + 4 * (tid - w1); j < g.toKeep + g.F; j += 4 * WAVE)
-            fir4((const lds_f64 *)L.xs, (const lds_f64 *)L.st->a, g.orderPitch, j, g.toKeep + g.F, L.eF + nChunk * g.C);
-    }
+    if (tid >= w1 && tid < w1 + WAVE) fir_cont_wave(g, L, (const lds_f64 *)L.xs, nChunk);
     if (!noBarrier) __syncthreads();
     STAMP(d, 10);
     return true;
@@ -2000,6 +2055,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     L.ishare = (int *)((char *)smem + ((size_t)((lds_i32 *)(L.st + 1) - (lds_i32 *)smem)) * sizeof(int));
     L.xcA = (lds_f64 *)(L.st + 1) + 2;                // behind ishare's 16 bytes, in front of the FFT arrays
     L.lpcFlag = (int *)((char *)smem + ((size_t)((lds_i32 *)((lds_f64 *)(L.st + 1) + 3) - (lds_i32 *)smem)) * sizeof(int));
+    L.psFlag = L.lpcFlag + 1;
     L.fft = (lds_f64 *)(L.st + 1) + 8;                // [2 << fftLog] only when launched with the FFT extension
 
     // Everything the block needs from global memory is requested in ONE go (tracker state, the frame in
@@ -2039,13 +2095,14 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         }
     }
     if (nSteps > 0) load_xs(0, tid);
-    if (tid == 0) { L.ishare[3] = 0; *L.lpcFlag = 0; }   // flags (generation counters): YIN prefix sums, LPC coefficients
+    if (tid == 0) { L.ishare[3] = 0; *L.lpcFlag = 0; *L.psFlag = 0; }   // flags (generation counters): YIN prefix sums, LPC coefficients, grain table
     __syncthreads();
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
     const bool hValid0 = frameLive0 && (g.C & 63) == 0 && g.orderPitch < WAVE;
 
     bool qValid = false, hValid = hValid0;
-    int xcGenCtr = 0;
+    int xcGenCtr = 0, psGen = 0;
+    bool preDone = false;                             // the coming chunk's PSOLA has been done ahead (pitch_iir)
     // vp_process_blocks_device: several consecutive blocks in this launch.  The tracker state and the frame in flight
     // stay in LDS between them; per block only the input is ingested (rings, gate), the voice window staged and the
     // output emitted -- exactly what separate launches would do, minus their state round trips.
@@ -2080,11 +2137,13 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
             if (sub == 0) {
                 if (nChunk == 0) continue;
                 nC = nChunk;
-                mode = pitch_chunk_cont_pre(g, c, d, L, nChunk, pS, s, qValid) ? 2 : 0;   // qValid: PSOLA starts with the grain table
+                if (preDone) mode = 2;         // residual, grain table and second pass were done beside the previous chunk's IIR
+                else mode = pitch_chunk_cont_pre(g, c, d, L, nChunk, pS, s, qValid) ? 2 : 0;   // qValid: PSOLA starts with the grain table
                 if (mode == 2 && nChunk == g.cpf - 1) {
                     // a new frame starts in this step: leave this chunk's IIR + output to wave 0 during
                     // the new frame's YIN phase (pitch_chunk_start_pre)
-                    psola(g, d, L, nC, pS, qValid);
+                    if (!preDone) psola(g, d, L, nC, pS, qValid);
+                    preDone = false;
                     pendingCont = nC;
                     continue;
                 }
@@ -2097,9 +2156,15 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
             if (mode == 2) {
-                psola(g, d, L, nC, pS, qValid);
-                pitch_iir<LITE, FAST>(g, d, L, nC, hValid);
-            }
+                if (!preDone) psola(g, d, L, nC, pS, qValid);
+                preDone = false;
+                // the frame's next chunk: handled by the next step of this block, window staged?
+                const bool ahead = qValid && nC + 1 <= g.cpf - 1 && step + 1 < nSteps && (step + 1) / g.xsSteps == step / g.xsSteps &&
+                                   nt >= 2 * WAVE;
+                pitch_iir<LITE, FAST>(g, d, L, nC, hValid, ahead, (const lds_f64 *)(xsAll + ((step + 1) % g.xsSteps) * g.C), pS + g.C, psGen);
+                preDone = ahead;
+            } else
+                preDone = false;
             if (mode >= 1) pitch_fill_output(g, c, d, L, nC, boff + pS, s);
             __syncthreads();
         }
