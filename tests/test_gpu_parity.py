@@ -2,6 +2,8 @@
 The kernels reproduce the reference's double arithmetic operation by operation, so the bar is
 BIT-EXACT float32 output and identical pitch-tracker state (period, marks, LPC coefficients).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -687,3 +689,49 @@ def test_certified_yin_random_configurations(seed):
         p.set_yin_mode(mode)
         outs.append(p.run(x))
     _assert_equal(outs[1], outs[0], f"seed {seed}: fs={fs} N={N} {params}")
+
+
+@pytest.mark.parametrize("seed", [0, 2, 5, 7, 11, 13, 14])
+def test_randomised_configurations_fast_modes_against_exact(seed):
+    """The bench's modes (FAST IIR + certified XCORR YIN) at random sample rates / block sizes / orders: output within the
+    tolerance of, and every pitch decision identical to, the library's default modes (which are bit-exact to the oracle)."""
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    fs, N, params = _fuzz_case(1000 + seed)
+    S = 3
+    T = max(6, int(26000 * fs / 44100.0) // N) * N
+    x = _streams(S, T, fs=fs)
+    outs, states = [], []
+    for iir, yin in (("exact", "direct"), ("fast", "xcorr")):
+        p = BatchVocoderProcessor(**params)
+        try:
+            p.prepareToPlay(fs, N, S)
+        except VpError:
+            pytest.skip("geometry exceeds the LDS budget")
+        p.set_iir_mode(iir)
+        p.set_yin_mode(yin)
+        outs.append(p.run(x).astype(np.float64))
+        states.append([p.pitch_state(s_) for s_ in range(S)])
+    err = outs[1] - outs[0]
+    rms = np.sqrt((err ** 2).mean())
+    assert rms < RMS_TOL, (rms, fs, N, params)
+    for s_ in range(S):
+        for k in ("period", "prevPeriod", "prevVoicedPeriod", "periodNew", "pitch", "beta", "anMarks", "stMarks", "gateOpen"):
+            assert np.array_equal(states[1][s_][k], states[0][s_][k]), (seed, s_, k)
+
+
+def test_no_read_of_unwritten_lds():
+    """LDS is not cleared between kernels: a read of a location the launch has not written returns what the previous
+    kernel on that CU left there -- usually a harmless finite number, once in a while a NaN (this is how a 16th history
+    tap with a zero coefficient made the FAST IIR emit NaNs in one run out of five).  The -DVP_POISON_LDS build fills
+    the dynamic LDS with NaNs at the top of every kernel; the whole GPU suite must pass on it."""
+    import subprocess
+    import sys
+    from vocoderproject_amd import build
+    if not os.path.exists(build.LIB_POISON):
+        pytest.skip("libvp_amd_poison.so not built (python -m vocoderproject_amd.build --poison)")
+    if os.environ.get("VP_AMD_LIB"):
+        pytest.skip("already running on a diagnostic library")
+    env = dict(os.environ, VP_AMD_LIB=build.LIB_POISON)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.dirname(os.path.abspath(__file__)), "-m", "gpu", "-q", "-x",
+                        "-k", "not unwritten_lds", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

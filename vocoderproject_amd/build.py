@@ -32,19 +32,25 @@ def needs_build():
 
 
 LIB_STAMPS = os.path.join(HERE, "libvp_amd_stamps.so")
+LIB_POISON = os.path.join(HERE, "libvp_amd_poison.so")
 
 
-def build(force=False, verbose=False, stamps=False):
+def build(force=False, verbose=False, stamps=False, poison=False):
     """stamps=True builds the DIAGNOSTIC library (in-kernel phase timers, -DVP_STAMPS) next to the
-    product one; it is only ever loaded through VP_AMD_LIB by tools/phase_stamps.py."""
-    lib = LIB_STAMPS if stamps else LIB
-    if not stamps and not force and not needs_build():
+    product one; it is only ever loaded through VP_AMD_LIB by tools/phase_stamps.py.
+    poison=True builds the other diagnostic library (-DVP_POISON_LDS: every kernel first fills its LDS with
+    NaNs, so a read of LDS the launch has not written fails the parity tests deterministically instead of
+    depending on what the previous kernel left on that CU); tests/test_gpu_parity.py runs the suite on it."""
+    lib = LIB_STAMPS if stamps else LIB_POISON if poison else LIB
+    if not stamps and not poison and not force and not needs_build():
         return LIB
     cmd = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
            f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if stamps:
         cmd.append("-DVP_STAMPS")
+    if poison:
+        cmd.append("-DVP_POISON_LDS")
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     cmd += ["-o", lib]
     if verbose:
@@ -54,4 +60,4 @@ def build(force=False, verbose=False, stamps=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv, poison="--poison" in sys.argv))

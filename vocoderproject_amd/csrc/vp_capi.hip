@@ -541,6 +541,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             ProfScope ps(h, st, 1);
             int nw = std::min(h->vocWaves, c.nWin);
             if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
+            cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
             hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(64 * nw), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
         }
         if (runPitch) {
@@ -554,6 +555,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
             if (nBlocks > 1) k = cp.iirFast ? vp_k_pitch_fast_multi : vp_k_pitch_multi;       // never with `lite` (see the caller)
+            cp.ldsBytes = (int)lds;
             hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);
         }
     }

@@ -45,6 +45,7 @@ struct VpCall {
     int yinFft;                  // 1: FFT accelerator for the YIN difference function + LPC autocorrelation
     int yinCert;                 // 1: cross-correlation form of the difference function (fused multiply-adds)
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
+    int ldsBytes;                // dynamic LDS of this launch (used by the -DVP_POISON_LDS diagnostic build only)
     int nBlocks;                 // pitch kernel with both fusions: consecutive blocks handled by this launch (>= 1);
                                  // the counters above describe the first, the kernel advances them itself
 };

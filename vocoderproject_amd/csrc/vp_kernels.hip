@@ -61,6 +61,16 @@ __device__ unsigned long long vp_last_w[16];
 #define VP_XC_ACSPLIT 11        /* sixteenths of the LPC autocorrelation summed beside the cross-correlation YIN */
 #endif
 
+// Diagnostic build (-DVP_POISON_LDS=bytes): every kernel starts by filling its dynamic LDS with signalling garbage (NaNs),
+// so that a read of LDS the launch has not written -- which otherwise returns whatever the previous kernel on that CU
+// left there -- shows up deterministically in the parity tests.
+#ifdef VP_POISON_LDS
+#define VP_POISON(SMEM, BYTES) do { for (int i_ = threadIdx.x; i_ < (int)((BYTES) / 8); i_ += blockDim.x) \
+        ((unsigned long long *)(SMEM))[i_] = 0x7ff8dead0000beefULL; __syncthreads(); } while (0)
+#else
+#define VP_POISON(SMEM, BYTES) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 
@@ -648,7 +658,9 @@ __device__ __forceinline__ void iir_block_wave_regs(const lds_f64 *x, lds_f64 *y
         // y[b - k] is lane 16 - k of the row
         const bool hist = (b > 0) || haveHist0;
         double Y3 = 0.0;
-        if (hist) Y3 = y[b - 16 + m];
+        // (only the last `order` outputs are history: older ones are not even restored when the frame continues in a
+        // later launch, and a zero coefficient does not neutralise a NaN left in LDS by somebody else)
+        if (hist && 16 - m <= order) Y3 = y[b - 16 + m];
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         VP_BI_ROW(X1, 1)
         VP_BI_ROW(X2, 2)
@@ -858,6 +870,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
+    VP_POISON(smem, c.ldsBytes);
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     vocoder_block(g, c, d, smem);
     if (c.fuseEmit) {
@@ -1375,7 +1388,11 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
             iir_fast_wave(xp, hpad + WAVE, WAVE, (const lds_f64 *)L.st->a, order, (const lds_f64 *)nullptr, 1.0);
             hValid = true;
         }
+#ifdef VP_DIAG_NO_REGS_IIR
+        if (false)
+#else
         if (!LITE && order <= 16)
+#endif
             iir_block_wave_regs((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, shift > 0, hpad);
         else
             iir_block_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, xp, 1.0);
@@ -1402,21 +1419,22 @@ __device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const
                                           const lds_f64 *xsNext, int pSNext, int &psGen)
 {
     const int tid = vp_tid(), nt = blockDim.x;
-    const int gen = ahead ? ++psGen : 0;
+    const int gen = ahead ? (psGen += 2) : 0;       // the flag counts two producers per use
     if (tid < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
     else if (ahead) {
-        if (tid < 2 * WAVE) {
-            fir_cont_wave(g, L, xsNext, nChunk + 1);
-            psola_table_wave(g, d, L, nChunk + 1, pSNext);
+        const int wv = tid >> 6, nw = nt >> 6;
+        const bool two = nw >= 3;                        // residual on wave 2, grain table on wave 1, side by side
+        if (wv == 1 || (two && wv == 2)) {
+            if (!two || wv == 2) fir_cont_wave(g, L, xsNext, nChunk + 1);
+            if (wv == 1) psola_table_wave(g, d, L, nChunk + 1, pSNext);
             __threadfence_block();
-            if (tid == WAVE) __hip_atomic_store(L.psFlag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((tid & 63) == 0) __hip_atomic_fetch_add(L.psFlag, two ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         int spin = 0;                                  // bounded: a bug shows as a parity failure and a count, never as a hang
         for (; spin < (1 << 22) && __hip_atomic_load(L.psFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen; spin++)
             __builtin_amdgcn_s_sleep(1);
         if (spin == (1 << 22) && (tid & 63) == 0) atomicAdd(&d.dbg[61], 1ULL);
         // (wave 4 shares wave 0's SIMD and stays out of the recursion's way)
-        const int wv = tid >> 6, nw = nt >> 6;
         if (nw != 8) psola_pass2(g, L, tid - WAVE, nt - WAVE, (nChunk + 1) * g.C);
         else if (wv != 4) psola_pass2(g, L, (wv < 4 ? wv - 1 : wv - 2) * WAVE + (tid & 63), 6 * WAVE, (nChunk + 1) * g.C);
     }
@@ -2034,6 +2052,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     int boff = 0, nSteps = c.nSteps;
     const float *in = in0;
     float *out = out0;
+    VP_POISON(smem, c.ldsBytes);
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
     PitchLds L;
     // voice window of g.xsSteps consecutive chunk steps; shifted by one double when needed so that
@@ -2159,8 +2178,10 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 if (!preDone) psola(g, d, L, nC, pS, qValid);
                 preDone = false;
                 // the frame's next chunk: handled by the next step of this block, window staged?
+                // (and the grain table must fit inside the yinTemp scratch: at low sample rates it spills into cum[], where
+                // the exact recursion keeps its history while it runs)
                 const bool ahead = qValid && nC + 1 <= g.cpf - 1 && step + 1 < nSteps && (step + 1) / g.xsSteps == step / g.xsSteps &&
-                                   nt >= 2 * WAVE;
+                                   nt >= 2 * WAVE && g.tauMax + 1 >= 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2;
                 pitch_iir<LITE, FAST>(g, d, L, nC, hValid, ahead, (const lds_f64 *)(xsAll + ((step + 1) % g.xsSteps) * g.C), pS + g.C, psGen);
                 preDone = ahead;
             } else
