@@ -735,3 +735,25 @@ def test_no_read_of_unwritten_lds():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.dirname(os.path.abspath(__file__)), "-m", "gpu", "-q", "-x",
                         "-k", "not unwritten_lds", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_two_handles_of_different_geometry_coexist():
+    """Per-function launch attributes (the dynamic-LDS ceiling) are process-wide: preparing a second, smaller handle must
+    not break the first one."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    big = BatchVocoderProcessor()
+    big.prepareExplicit(48000.0, 2048, 2, 2048, 1536, 2048, 512)       # cfg5 geometry: ~150 KB of LDS per workgroup
+    small = BatchVocoderProcessor()
+    small.prepareToPlay(22050.0, 256, 2)
+    xb = _streams(2, 2048 * 6, fs=48000.0)
+    xs = _streams(2, 256 * 24, fs=22050.0)
+    yb = big.run(xb)                                                     # launched AFTER the small handle was prepared
+    ys = small.run(xs)
+    _assert_equal(yb, _oracle_run(xb, 2048, dict(), prepare=(48000.0, 2048, 2048, 1536, 2048, 512)), "big")
+    ref = []
+    from oracle import oracle_py as O
+    for s_ in range(2):
+        o = O.OracleStream()
+        o.prepare_to_play(22050.0, 256)
+        ref.append(o.run(xs[s_]))
+    _assert_equal(ys, np.stack(ref), "small")

@@ -355,7 +355,8 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     // LDS budgets
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-    const size_t ldsMax = std::min<size_t>((size_t)prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536, 160 * 1024);
+    // (minus the kernels' few static reduction slots, which come out of the same 160 KB)
+    const size_t ldsMax = std::min<size_t>((size_t)prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536, 160 * 1024) - 256;
     // stage the voice window of as many consecutive chunk steps as fit comfortably (the whole block if possible)
     g.xsSteps = 1;
     {
@@ -384,17 +385,18 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     if (vp_voc_lds_bytes(W, nw) > ldsMax) { h->lastError = "vocoder window does not fit LDS"; return VP_ERR_GEOMETRY; }
     h->vocWaves = nw;
     h->vocLds = vp_voc_lds_bytes(W, nw);
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_fast, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_fast_multi, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(h->pitchLds + vp_pitch_fft_lds_bytes(g))));
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_lite, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_pitch_lite_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pitchLds));
-    HIPCHK(h, hipFuncSetAttribute((const void *)vp_k_vocoder, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->vocLds));
+    // the dynamic-LDS ceiling is a property of the FUNCTION, shared by every handle of the process: always the device's
+    // maximum, never this handle's own need (a later prepare of a smaller geometry must not lower it under another handle)
+    {
+        const void *fns[] = {(const void *)vp_k_pitch, (const void *)vp_k_pitch_fast, (const void *)vp_k_pitch_multi,
+                             (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
+                             (const void *)vp_k_vocoder};
+        for (const void *f : fns) {
+            hipFuncAttributes fa;
+            HIPCHK(h, hipFuncGetAttributes(&fa, f));                        // the static part (a few reduction slots) comes off the top
+            HIPCHK(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ldsMax + 256 - fa.sharedSizeBytes)));
+        }
+    }
 
     VpDev d;
     memset(&d, 0, sizeof d);
