@@ -1372,6 +1372,61 @@ __device__ __forceinline__ void fir_cont_wave(const VpGeom &g, const PitchLds &L
         fir4(xsStep, (const lds_f64 *)L.st->a, g.orderPitch, j, g.toKeep + g.F, L.eF + nChunk * g.C);
 }
 
+// The EXACT all-pole recursion y[i] = x[i] - sum_{k=1..order} a[k] y[i-k] for orders <= 16, by one full wavefront, in the
+// reference's operation order (product rounded, then subtracted, k = 1, 2, ...), organised around the DPP row broadcast:
+//   * lane m of every 16-lane row holds the output y[i-1-m] (Yh) and the coefficient a[m+1]: ONE v_mul_f64 gives all
+//     the sample's products t_k = a[k] y[i-k], each correctly rounded, instead of `order` multiplies issued in between
+//     the chain's subtractions (an fp64 op issued in front of a dependent one is not hidden, section 4.2);
+//   * the chain acc -= t_k is v_fmac_f64 acc, bcast(T, k-1), -1.0: t * (-1) is exact, so the fused operation rounds
+//     exactly like the subtraction;
+//   * the new output enters Yh through a DPP row shift (lane 0 of each row takes acc), inputs are read and outputs
+//     written sixteen at a time.
+// hist[j] = y[-1-j] (j < order) or nullptr.  n a multiple of 16.
+// (the order is a template parameter: a wave-uniform branch per tap cost three times the tap itself)
+#define VP_XR_TAP(K) if ((K) <= ORD) { VP_FMAC_BCAST(acc, T, mone, (K) - 1); }
+template <int ORD, class XP, class YP, class AP, class HP>
+__device__ __forceinline__ void iir_exact_row16_t(XP x, YP y, int n, AP aL, HP hist, double gmul)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    constexpr int order = ORD;
+    const double A = (m + 1 <= order) ? aL[m + 1] : 0.0;
+    const double mone = -1.0, zero = 0.0;
+    double Yh = (hist && m < order) ? hist[m] : 0.0;
+    for (int i0 = 0; i0 < n; i0 += 16) {
+        const double X = x[i0 + m];                                         // sixteen inputs, one per lane of the row
+        double Yout = 0.0;                                                  // the sixteen outputs, gathered the same way
+#define VP_XR_SAMPLE(U) { \
+            double T = Yh * A;                                              /* t_k for every k at once */ \
+            double acc = zero * zero;                                       /* +0.0 in a fresh register */ \
+            asm volatile("s_nop 1" : "+v"(T), "+v"(acc));                   /* VALU write -> DPP read */ \
+            VP_FMAC_BCAST(acc, X, gmul, U);                                 /* acc = gmul * x[i0+U] (one rounding, as the product) */ \
+            VP_XR_TAP(1) VP_XR_TAP(2) VP_XR_TAP(3) VP_XR_TAP(4) VP_XR_TAP(5) VP_XR_TAP(6) VP_XR_TAP(7) VP_XR_TAP(8) \
+            VP_XR_TAP(9) VP_XR_TAP(10) VP_XR_TAP(11) VP_XR_TAP(12) VP_XR_TAP(13) VP_XR_TAP(14) VP_XR_TAP(15) VP_XR_TAP(16) \
+            if (m == (U)) Yout = acc; \
+            /* Yh[m] <- Yh[m-1], Yh[0] <- acc: DPP row_shr:1, lane 0 of each row keeps `old` = acc */ \
+            const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(acc), __double2loint(Yh), 0x111, 0xf, 0xf, false); \
+            const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(acc), __double2hiint(Yh), 0x111, 0xf, 0xf, false); \
+            Yh = __hiloint2double(hi_, lo_); }
+        VP_XR_SAMPLE(0) VP_XR_SAMPLE(1) VP_XR_SAMPLE(2) VP_XR_SAMPLE(3) VP_XR_SAMPLE(4) VP_XR_SAMPLE(5) VP_XR_SAMPLE(6) VP_XR_SAMPLE(7)
+        VP_XR_SAMPLE(8) VP_XR_SAMPLE(9) VP_XR_SAMPLE(10) VP_XR_SAMPLE(11) VP_XR_SAMPLE(12) VP_XR_SAMPLE(13) VP_XR_SAMPLE(14) VP_XR_SAMPLE(15)
+#undef VP_XR_SAMPLE
+        y[i0 + m] = Yout;                                                   // (all four rows store the same values)
+    }
+}
+#undef VP_XR_TAP
+
+template <class XP, class YP, class AP, class HP>
+__device__ __forceinline__ void iir_exact_row16(XP x, YP y, int n, AP aL, int order_, HP hist, double gmul)
+{
+    switch (__builtin_amdgcn_readfirstlane(order_)) {
+#define VP_XR_CASE(O) case O: iir_exact_row16_t<O>(x, y, n, aL, hist, gmul); break;
+        VP_XR_CASE(2) VP_XR_CASE(3) VP_XR_CASE(4) VP_XR_CASE(5) VP_XR_CASE(6) VP_XR_CASE(7) VP_XR_CASE(8) VP_XR_CASE(9)
+        VP_XR_CASE(10) VP_XR_CASE(11) VP_XR_CASE(12) VP_XR_CASE(13) VP_XR_CASE(14) VP_XR_CASE(15) VP_XR_CASE(16)
+#undef VP_XR_CASE
+        default: break;                                                      // orders are 2..100 (params_valid); > 16 never comes here
+    }
+}
+
 // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
 // all 64 lanes run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
 template <bool LITE, bool FAST>
@@ -1406,6 +1461,8 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
         const int nh = min(order, shift);
         for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
         if (FAST) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
+        else if (order <= 16 && (g.C & 15) == 0)
+            iir_exact_row16(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
         else iir_exact<LITE>(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
 }
