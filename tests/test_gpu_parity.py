@@ -757,3 +757,17 @@ def test_two_handles_of_different_geometry_coexist():
         o.prepare_to_play(22050.0, 256)
         ref.append(o.run(xs[s_]))
     _assert_equal(ys, np.stack(ref), "small")
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 14, 15, 16, 17, 24])
+def test_exact_iir_every_small_order(order):
+    """The EXACT pitch-path recursion has one instantiation per order up to 16 (DPP-row form) and the general form above:
+    bit-exact against the oracle for each, at two block sizes (chunk boundaries fall differently)."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    for N in (1024, 300):
+        S, B = 3, 12 if N == 1024 else 40
+        x = _streams(S, N * B)
+        params = dict(lpcPitch=order, vocBool=0)
+        p = BatchVocoderProcessor(**params)
+        p.prepareToPlay(FS, N, S)
+        _assert_equal(p.run(x), _oracle_run(x, N, params), f"lpcPitch={order} N={N}")
