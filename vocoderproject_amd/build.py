@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "libvp_amd.so")
 SOURCES = ["vp_kernels.hip", "vp_capi.hip"]
 DEPS = SOURCES + ["vp_common.h", "vp_kernels.h"]
 ARCH = "gfx950"
+NUM_TUS = 5          # groups of kernels in vp_kernels.hip (VP_TU)
 
 
 def hipcc():
@@ -44,18 +45,34 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     lib = LIB_STAMPS if stamps else LIB_POISON if poison else LIB
     if not stamps and not poison and not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-           f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    # vp_kernels.hip is compiled as NUM_TUS translation units side by side (each keeps one group of kernels, -DVP_TU=k),
+    # vp_capi.hip as one more; then one link.  (One hipcc process for everything took 90 s.)
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    common = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+              "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if stamps:
-        cmd.append("-DVP_STAMPS")
+        common.append("-DVP_STAMPS")
     if poison:
-        cmd.append("-DVP_POISON_LDS")
-    cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-o", lib]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        common.append("-DVP_POISON_LDS")
+    with tempfile.TemporaryDirectory(prefix="vp_build_") as tmp:
+        jobs = [(os.path.join(CSRC, "vp_kernels.hip"), os.path.join(tmp, f"k{k}.o"), [f"-DVP_TU={k}"]) for k in range(1, NUM_TUS + 1)]
+        jobs.append((os.path.join(CSRC, "vp_capi.hip"), os.path.join(tmp, "capi.o"), []))
+
+        def compile_one(job):
+            src, obj, extra = job
+            cmd = common + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return obj
+
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            objs = list(ex.map(compile_one, jobs))
+        link = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", lib]
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
     return lib
 
 

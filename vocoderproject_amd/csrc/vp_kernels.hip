@@ -15,6 +15,16 @@
 
 #include "vp_common.h"
 
+// The kernels are template instantiations of two large bodies; the build compiles this file several times side by side,
+// each translation unit keeping one group of them (-DVP_TU=k; 0 or undefined: all of them, e.g. for -S listings).
+//   1: ingest/gate, vocoder, emit, STFT   2: vp_k_pitch   3: vp_k_pitch_fast, vp_k_pitch_fast_multi   4: vp_k_pitch_multi
+//   5: vp_k_pitch_lite, vp_k_pitch_lite_fast
+#ifndef VP_TU
+#define VP_TU 0
+#endif
+#define VP_TU_HAS(K) (VP_TU == 0 || VP_TU == (K))
+#define VP_NUM_TUS 5
+
 #define WAVE 64
 
 // explicit LDS address space: keeps the compiler on ds_read/ds_write instead of flat accesses
@@ -174,10 +184,12 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
     __syncthreads();
 }
 
+#if VP_TU_HAS(1)
 __global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in)
 {
     ingest_gate_block(g, c, d, in);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Wave-uniform broadcast of a double held by lane `src` (src is wave-uniform): two v_readlane_b32.
@@ -867,6 +879,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 // Per launch the host may fold the ingest+gate prologue and/or the emit epilogue into this kernel
 // (c.fuseIngest / c.fuseEmit): every stage is one-workgroup-per-stream, so the fusion only removes
 // kernel boundaries (~10 us each at this size), not parallelism.
+#if VP_TU_HAS(1)
 __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
@@ -878,6 +891,7 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d,
         emit_block(g, c, d, out);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Radix-2 complex FFT in LDS (double), whole workgroup, M = 1 << logM points, split re/im arrays.
@@ -2283,50 +2297,62 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
 // register-resident instantiations and the block form's 64 resident taps never meet in one register
 // allocation (together they pushed kernel-invariant values into scratch, and every reload in a serial
 // phase is a memory round trip), and each build carries half the code.
+#if VP_TU_HAS(2)
 __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
     pitch_kernel_body<false, false, false>(g, c, d, in, out, smem);
 }
+#endif
 
+#if VP_TU_HAS(3)
 __global__ __launch_bounds__(512) void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                        float *__restrict__ out)
 {
     extern __shared__ double smem[];
     pitch_kernel_body<false, true, false>(g, c, d, in, out, smem);
 }
+#endif
 
 // vp_process_blocks_device: the same two, looping over c.nBlocks consecutive blocks (state stays in LDS between them)
+#if VP_TU_HAS(4)
 __global__ __launch_bounds__(512) void vp_k_pitch_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                         float *__restrict__ out)
 {
     extern __shared__ double smem[];
     pitch_kernel_body<false, false, true>(g, c, d, in, out, smem);
 }
+#endif
 
+#if VP_TU_HAS(3)
 __global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                              float *__restrict__ out)
 {
     extern __shared__ double smem[];
     pitch_kernel_body<false, true, true>(g, c, d, in, out, smem);
 }
+#endif
 
 // Register-light build of the same kernel (<= 128 VGPRs: two 512-thread workgroups per CU), selected by the
 // host for large batches when the exact IIR needs no big register-resident instantiation (FAST mode, or
 // lpcPitch <= 16).  With S >> 256 streams a second resident workgroup fills the first one's serial phases.
+#if VP_TU_HAS(5)
 __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                            float *__restrict__ out)
 {
     extern __shared__ double smem[];
     pitch_kernel_body<true, false, false>(g, c, d, in, out, smem);
 }
+#endif
 
+#if VP_TU_HAS(5)
 __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                                 float *__restrict__ out)
 {
     extern __shared__ double smem[];
     pitch_kernel_body<true, true, false>(g, c, d, in, out, smem);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // K3: emit.  addDryVoice / addSynth (MyBuffer.cpp:309-448) + fillOutputBuffer + clearOutput
@@ -2359,10 +2385,12 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
     }
 }
 
+#if VP_TU_HAS(1)
 __global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out)
 {
     emit_block(g, c, d, out);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Standalone STFT round trip (NO reference counterpart -- the reference has no FFT, SURVEY.md section 0;
@@ -2370,6 +2398,7 @@ __global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, fl
 // north_star names, reported separately).  One workgroup per (stream, frame): sqrt-Hann analysis
 // window, forward FFT, [identity spectral stage, optional magnitude dump], inverse FFT, sqrt-Hann
 // synthesis window -> frame scratch; a second kernel overlap-adds in gather form (deterministic).
+#if VP_TU_HAS(1)
 __global__ __launch_bounds__(256) void vp_k_stft_frames(const float *__restrict__ in, float *__restrict__ frames,
                                                         float *__restrict__ mag, const double *__restrict__ win,
                                                         const double *__restrict__ twRe, const double *__restrict__ twIm,
@@ -2393,7 +2422,9 @@ __global__ __launch_bounds__(256) void vp_k_stft_frames(const float *__restrict_
     const double invF = 1.0 / (double)F;
     for (int j = tid; j < F; j += nt) o[j] = (float)(zr[j] * invF * win[j]);
 }
+#endif
 
+#if VP_TU_HAS(1)
 __global__ __launch_bounds__(256) void vp_k_stft_ola(const float *__restrict__ frames, float *__restrict__ out, int nSamples,
                                                      int nFrames, int F, int hop, float scale)
 {
@@ -2408,3 +2439,4 @@ __global__ __launch_bounds__(256) void vp_k_stft_ola(const float *__restrict__ f
         out[(size_t)s * nSamples + t] = acc * scale;
     }
 }
+#endif
