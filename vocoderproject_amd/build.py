@@ -45,8 +45,8 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     lib = LIB_STAMPS if stamps else LIB_POISON if poison else LIB
     if not stamps and not poison and not force and not needs_build():
         return LIB
-    # vp_kernels.hip is compiled as NUM_TUS translation units side by side (each keeps one group of kernels, -DVP_TU=k),
-    # vp_capi.hip as one more; then one link.  (One hipcc process for everything took 90 s.)
+    # vp_kernels.hip can be compiled as NUM_TUS translation units side by side (each keeps one group of kernels, -DVP_TU=k),
+    # vp_capi.hip is one more; then one link.  (One translation unit takes 90 s, the groups 40 s.)
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     common = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -55,8 +55,12 @@ def build(force=False, verbose=False, stamps=False, poison=False):
         common.append("-DVP_STAMPS")
     if poison:
         common.append("-DVP_POISON_LDS")
+    # The PRODUCT library keeps vp_kernels.hip in one translation unit: measured on the same box, the same kernels run
+    # 1.3 % slower out of per-group code objects (instruction placement; tools/ab.sh).  The diagnostic twins take the
+    # fast build.
+    groups = [0] if not (stamps or poison) else list(range(1, NUM_TUS + 1))
     with tempfile.TemporaryDirectory(prefix="vp_build_") as tmp:
-        jobs = [(os.path.join(CSRC, "vp_kernels.hip"), os.path.join(tmp, f"k{k}.o"), [f"-DVP_TU={k}"]) for k in range(1, NUM_TUS + 1)]
+        jobs = [(os.path.join(CSRC, "vp_kernels.hip"), os.path.join(tmp, f"k{k}.o"), [f"-DVP_TU={k}"]) for k in groups]
         jobs.append((os.path.join(CSRC, "vp_capi.hip"), os.path.join(tmp, "capi.o"), []))
 
         def compile_one(job):

@@ -17,7 +17,7 @@
 
 // The kernels are template instantiations of two large bodies; the build compiles this file several times side by side,
 // each translation unit keeping one group of them (-DVP_TU=k; 0 or undefined: all of them, e.g. for -S listings).
-//   1: ingest/gate, vocoder, emit, STFT   2: vp_k_pitch   3: vp_k_pitch_fast, vp_k_pitch_fast_multi   4: vp_k_pitch_multi
+//   1: ingest/gate, vocoder, emit, STFT   2: vp_k_pitch   3: vp_k_pitch_fast   4: vp_k_pitch_multi, vp_k_pitch_fast_multi
 //   5: vp_k_pitch_lite, vp_k_pitch_lite_fast
 #ifndef VP_TU
 #define VP_TU 0
@@ -2324,7 +2324,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch_multi(VpGeom g, VpCall c, VpDe
 }
 #endif
 
-#if VP_TU_HAS(3)
+#if VP_TU_HAS(4)
 __global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                              float *__restrict__ out)
 {
