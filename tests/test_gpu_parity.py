@@ -516,7 +516,9 @@ def test_pitch_kernel_build_selection():
     q.set_iir_mode("fast")
     assert q.pitch_kernel_name() == "vp_k_pitch_lite_fast"
     q.set_yin_mode("fft")
-    assert q.pitch_kernel_name() == "vp_k_pitch_fast"            # the FFT accelerator needs the full build's LDS
+    assert q.pitch_kernel_name() == "vp_k_pitch_fast_fft"        # the FFT accelerator has builds of its own (never the light one)
+    q.set_iir_mode("exact")
+    assert q.pitch_kernel_name() == "vp_k_pitch_fft"
 
 
 def test_long_run_with_random_parameter_schedule():

@@ -88,6 +88,7 @@ extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
     const bool fast = h->iirMode == VP_IIR_FAST, lite = pitch_lite(h, fast, h->yinMode == VP_YIN_FFT);
+    if (h->yinMode == VP_YIN_FFT && h->g.fftLog > 0) return fast ? "vp_k_pitch_fast_fft" : "vp_k_pitch_fft";
     return lite ? (fast ? "vp_k_pitch_lite_fast" : "vp_k_pitch_lite") : (fast ? "vp_k_pitch_fast" : "vp_k_pitch");
 }
 
@@ -390,6 +391,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     {
         const void *fns[] = {(const void *)vp_k_pitch, (const void *)vp_k_pitch_fast, (const void *)vp_k_pitch_multi,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
+                             (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
                              (const void *)vp_k_vocoder};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -556,7 +558,8 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             const bool lite = pitch_lite(h, cp.iirFast != 0, cp.yinFft != 0);
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
-            if (nBlocks > 1) k = cp.iirFast ? vp_k_pitch_fast_multi : vp_k_pitch_multi;       // never with `lite` (see the caller)
+            if (nBlocks > 1) k = cp.iirFast ? vp_k_pitch_fast_multi : vp_k_pitch_multi;       // never with `lite` or FFT (see the caller)
+            if (cp.yinFft) k = cp.iirFast ? vp_k_pitch_fast_fft : vp_k_pitch_fft;              // (never `lite`: pitch_lite())
             cp.ldsBytes = (int)lds;
             hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);
         }
@@ -599,7 +602,7 @@ extern "C" int vp_process_blocks_device(vp_handle *h, const float *d_in, float *
     if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     const vp_params &P = h->params;
     const bool fast = h->iirMode == VP_IIR_FAST, fft = h->yinMode == VP_YIN_FFT && h->g.fftLog > 0;
-    if (P.pitchBool && !P.vocBool && n_blocks > 1 && !pitch_lite(h, fast, fft))   // one launch: state stays on chip between the blocks
+    if (P.pitchBool && !P.vocBool && n_blocks > 1 && !fft && !pitch_lite(h, fast, fft))   // one launch: state stays on chip between the blocks
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks);
     const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
     for (int b = 0; b < n_blocks; b++) {                       // other plans: block by block

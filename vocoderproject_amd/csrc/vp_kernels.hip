@@ -1702,7 +1702,7 @@ __device__ __forceinline__ bool pitch_can_overlap(const VpGeom &g)
 // its residual and PSOLA done but not yet its IIR + output; wave 0 runs them here, next to the new
 // frame's YIN on the other waves (they touch disjoint data: the old frame's outEFrame/yFrame and
 // coefficients versus xs/yinTemp), and the new frame's buffers are zeroed only afterwards.
-template <bool LITE, bool FAST>
+template <bool LITE, bool FAST, bool FFT>
 __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
                                                      int pS, int s, int pendingCont, bool &hValid, int &xcGenCtr)
 {
@@ -1728,11 +1728,12 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         L.ishare[1] = 0;                                                     // "a comparison was too close to call" (yin_pick)
     }
     // LPC ahead of the pitch decisions (see below): needs the time-domain autocorrelation on one wavefront
-    const bool specLpc = !c.yinFft && g.orderPitch < WAVE && nt >= 8 * WAVE;
+    const bool yinFft = FFT && c.yinFft;              // (only the *_fft builds carry that path)
+    const bool specLpc = !yinFft && g.orderPitch < WAVE && nt >= 8 * WAVE;
     // VP_YIN_XCORR: cross-correlation form of the difference function, certified (yin_pick) with the reference's
     // arithmetic as the fallback; needs the two-lags-per-lane layout on waves 1..4 and a free wave 5
     const int yNPairs = (g.tauMax + 1) >> 1, yWaves = (yNPairs + WAVE - 1) / WAVE;
-    const int xcCert = (c.yinCert != 0 && !c.yinFft && (g.C & 1) == 0 && yWaves <= 4 && nt == 8 * WAVE) ? c.yinCert : 0;
+    const int xcCert = (c.yinCert != 0 && !yinFft && (g.C & 1) == 0 && yWaves <= 4 && nt == 8 * WAVE) ? c.yinCert : 0;
     const bool levLate = xcCert != 0;                 // Levinson-Durbin at the top of the marks phase instead of beside the running sum
     const int acM = min(nt - 1 - tid, g.orderPitch);                         // the last wavefront's lag per lane
     // how much of the sum runs beside YIN (the cross-correlation form of YIN is shorter: less fits beside it)
@@ -1742,12 +1743,12 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     STAMPW_BEGIN();
     {
         const int base = g.toKeep - g.tauMax;
-        if (pendingCont >= 0 && (!pitch_can_overlap(g) || c.yinFft)) {      // no free wave: finish the old frame first
+        if (pendingCont >= 0 && (!pitch_can_overlap(g) || yinFft)) {      // no free wave: finish the old frame first
             if (tid < WAVE) { pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
             __syncthreads();
             pendingCont = -1;
         }
-        if (c.yinFft) {
+        if (yinFft) {
             // VP_YIN_FFT (accelerator, not bit-exact): with a = frame (F samples, zero padded) and
             // b = the window of F + tauMax samples the difference function reads,
             //   d[k] = sum a_i^2 + sum_{j=k}^{k+F-1} b_j^2 - 2 (a (x) b)[k],
@@ -1956,7 +1957,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
 #ifdef VP_DIAG_NO_AUTOCORR
         if (false)
 #endif
-        if (!c.yinFft)
+        if (!yinFft)
         // highest threads (they have no YIN lag), again whole wavefronts: spare lanes redo lag `order`
         for (int m0 = nt - 1 - tid; (m0 & ~(WAVE - 1)) <= order && m0 >= 0; m0 += nt) {
             const int m = min(m0, order);
@@ -2109,7 +2110,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     return 1;
 }
 
-template <bool LITE, bool FAST, bool MULTI>
+template <bool LITE, bool FAST, bool MULTI, bool FFT>
 __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in0,
                                                   float *__restrict__ out0, double *smem)
 {
@@ -2241,7 +2242,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre<LITE, FAST>(g, c, d, L, boff + pS, s, pendingCont, hValid, xcGenCtr);   // pS: output position only
+                mode = pitch_chunk_start_pre<LITE, FAST, FFT>(g, c, d, L, boff + pS, s, pendingCont, hValid, xcGenCtr);   // pS: output position only
                 hValid = (mode != 0) && (g.C & 63) == 0 && g.orderPitch < WAVE;    // computed there for the new coefficients
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
@@ -2301,7 +2302,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
 __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2310,7 +2311,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev
                                                        float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, true, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, true, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2320,7 +2321,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch_multi(VpGeom g, VpCall c, VpDe
                                                         float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, false, true>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false, true, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2329,7 +2330,23 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c,
                                                              float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, true, true>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, true, true, false>(g, c, d, in, out, smem);
+}
+#endif
+
+// VP_YIN_FFT (experimental accelerator, section 4.3) has builds of its own, so that the others do not carry its code
+#if VP_TU_HAS(4)
+__global__ __launch_bounds__(512) void vp_k_pitch_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, false, false, true>(g, c, d, in, out, smem);
+}
+
+__global__ __launch_bounds__(512) void vp_k_pitch_fast_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                           float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, true, false, true>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2341,7 +2358,7 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite(VpGeom g, VpCall c, Vp
                                                            float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true, false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, false, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2350,7 +2367,7 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall 
                                                                 float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true, true, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, true, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
