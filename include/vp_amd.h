@@ -169,7 +169,7 @@ int vp_profile_enable(vp_handle *h, int on);
 int vp_profile_read(vp_handle *h, double ms[VP_NUM_KERNEL_SLOTS], long launches[VP_NUM_KERNEL_SLOTS], int reset);
 const char *vp_kernel_slot_name(int slot);
 /* Symbol of the pitch-kernel build the handle's current geometry and modes select (slot 2 is one of
- * vp_k_pitch, vp_k_pitch_fast, vp_k_pitch_lite, vp_k_pitch_lite_fast, vp_k_pitch_fft, vp_k_pitch_fast_fft); "" before prepare. */
+ * vp_k_pitch[_fast][_c], vp_k_pitch_lite[_fast], vp_k_pitch[_fast]_fft; _c = the common-case builds); "" before prepare. */
 const char *vp_pitch_kernel_name(const vp_handle *h);
 
 /* Counts, over all streams since prepare, how often a kernel reached one of the reference's

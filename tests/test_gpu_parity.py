@@ -502,14 +502,19 @@ def test_randomised_configurations_bit_exact(seed):
 
 
 def test_pitch_kernel_build_selection():
-    """The four builds of the pitch kernel (IIR mode x register budget) are selected as documented."""
+    """The builds of the pitch kernel (IIR mode x register budget x common-case geometry x FFT) are selected as documented."""
     from vocoderproject_amd import BatchVocoderProcessor
     p = BatchVocoderProcessor(vocBool=0)
     assert p.pitch_kernel_name() == ""
     p.prepareToPlay(FS, 1024, 8)
-    assert p.pitch_kernel_name() == "vp_k_pitch"
+    assert p.pitch_kernel_name() == "vp_k_pitch_c"               # chunk of 256 samples, lpcPitch 15, tauMax 441: common case
     p.set_iir_mode("fast")
-    assert p.pitch_kernel_name() == "vp_k_pitch_fast"
+    assert p.pitch_kernel_name() == "vp_k_pitch_fast_c"
+    g = BatchVocoderProcessor(vocBool=0, lpcPitch=24)            # an order the common-case builds do not cover
+    g.prepareToPlay(FS, 1024, 8)
+    assert g.pitch_kernel_name() == "vp_k_pitch"
+    g.set_iir_mode("fast")
+    assert g.pitch_kernel_name() == "vp_k_pitch_fast"
     q = BatchVocoderProcessor(vocBool=0)
     q.prepareToPlay(FS, 1024, 300)
     assert q.pitch_kernel_name() == "vp_k_pitch_lite"

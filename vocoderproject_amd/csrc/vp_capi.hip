@@ -84,11 +84,18 @@ static bool pitch_lite(const vp_handle *h, bool iirFast, bool yinFft)
     return h->g.S > 256 && !yinFft && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024;
 }
 
+// geometry and order for which the common-case builds (vp_k_pitch*_c) are valid
+static bool pitch_common(const vp_handle *h)
+{
+    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512;
+}
+
 extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
     const bool fast = h->iirMode == VP_IIR_FAST, lite = pitch_lite(h, fast, h->yinMode == VP_YIN_FFT);
     if (h->yinMode == VP_YIN_FFT && h->g.fftLog > 0) return fast ? "vp_k_pitch_fast_fft" : "vp_k_pitch_fft";
+    if (!lite && pitch_common(h)) return fast ? "vp_k_pitch_fast_c" : "vp_k_pitch_c";
     return lite ? (fast ? "vp_k_pitch_lite_fast" : "vp_k_pitch_lite") : (fast ? "vp_k_pitch_fast" : "vp_k_pitch");
 }
 
@@ -392,6 +399,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         const void *fns[] = {(const void *)vp_k_pitch, (const void *)vp_k_pitch_fast, (const void *)vp_k_pitch_multi,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
                              (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
+                             (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c,
                              (const void *)vp_k_vocoder};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -558,6 +566,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             const bool lite = pitch_lite(h, cp.iirFast != 0, cp.yinFft != 0);
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
+            if (!lite && pitch_common(h)) k = cp.iirFast ? vp_k_pitch_fast_c : vp_k_pitch_c;    // the common-case builds
             if (nBlocks > 1) k = cp.iirFast ? vp_k_pitch_fast_multi : vp_k_pitch_multi;       // never with `lite` or FFT (see the caller)
             if (cp.yinFft) k = cp.iirFast ? vp_k_pitch_fast_fft : vp_k_pitch_fft;              // (never `lite`: pitch_lite())
             cp.ldsBytes = (int)lds;

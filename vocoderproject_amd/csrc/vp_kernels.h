@@ -12,6 +12,8 @@ __global__ void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev d, const float *__rest
 __global__ void vp_k_pitch_lite_fast(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);

@@ -1443,10 +1443,10 @@ __device__ __forceinline__ void iir_exact_row16(XP x, YP y, int n, AP aL, int or
 
 // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
 // all 64 lanes run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
-template <bool LITE, bool FAST>
+template <bool LITE, bool FAST, bool COMMON>
 __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &L, int nChunk, bool &hValid)
 {
-    if (FAST && (g.C & 63) == 0 && g.orderPitch < WAVE) {
+    if (FAST && (COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE))) {
         // block form; the impulse response of the frame's 1/A(z) lives in cum[128..256) (64 zeros in front)
         const int shift = nChunk * g.C, order = g.orderPitch;
         lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
@@ -1460,7 +1460,7 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
 #ifdef VP_DIAG_NO_REGS_IIR
         if (false)
 #else
-        if (!LITE && order <= 16)
+        if (COMMON || (!LITE && order <= 16))
 #endif
             iir_block_wave_regs((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, shift > 0, hpad);
         else
@@ -1475,13 +1475,13 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
         const int nh = min(order, shift);
         for (int j = 0; j < order; j++) hist[j] = (j < nh) ? L.yF[shift - 1 - j] : 0.0;
         if (FAST) iir_fast_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
-        else if (order <= 16 && (g.C & 15) == 0)
+        else if (COMMON || (order <= 16 && (g.C & 15) == 0))
             iir_exact_row16(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, 1.0);
         else iir_exact<LITE>(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, (const lds_f64 *)hist, shift, 1.0);
     }
 }
 
-template <bool LITE, bool FAST>
+template <bool LITE, bool FAST, bool COMMON>
 // The chunk's IIR on wave 0.  `ahead`: the frame's NEXT chunk belongs to the next step of this block and its voice
 // window (xsNext) is staged, so the other wavefronts do that chunk's residual FIR, grain table (wave 1, which then raises
 // a flag) and second PSOLA pass now instead of waiting: none of it touches what the recursion reads or writes (the
@@ -1491,7 +1491,7 @@ __device__ __forceinline__ void pitch_iir(const VpGeom &g, const VpDev &d, const
 {
     const int tid = vp_tid(), nt = blockDim.x;
     const int gen = ahead ? (psGen += 2) : 0;       // the flag counts two producers per use
-    if (tid < WAVE) pitch_iir_wave<LITE, FAST>(g, L, nChunk, hValid);
+    if (tid < WAVE) pitch_iir_wave<LITE, FAST, COMMON>(g, L, nChunk, hValid);
     else if (ahead) {
         const int wv = tid >> 6, nw = nt >> 6;
         const bool two = nw >= 3;                        // residual on wave 2, grain table on wave 1, side by side
@@ -1702,7 +1702,7 @@ __device__ __forceinline__ bool pitch_can_overlap(const VpGeom &g)
 // its residual and PSOLA done but not yet its IIR + output; wave 0 runs them here, next to the new
 // frame's YIN on the other waves (they touch disjoint data: the old frame's outEFrame/yFrame and
 // coefficients versus xs/yinTemp), and the new frame's buffers are zeroed only afterwards.
-template <bool LITE, bool FAST, bool FFT>
+template <bool LITE, bool FAST, bool FFT, bool COMMON>
 __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCall &c, const VpDev &d, const PitchLds &L,
                                                      int pS, int s, int pendingCont, bool &hValid, int &xcGenCtr)
 {
@@ -1711,7 +1711,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     const int tid = vp_tid(), nt = blockDim.x;
     if (!d.gate[s * 2 + 0]) {                                               // :208-214
         if (pendingCont >= 0) {
-            if (tid < WAVE) { pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+            if (tid < WAVE) { pitch_iir_wave<LITE, FAST, COMMON>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
         }
         __syncthreads();
         if (tid == 0) { st->nAn = 0; st->prevPitch = 0; st->gateOpen = 0; }
@@ -1729,11 +1729,11 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     }
     // LPC ahead of the pitch decisions (see below): needs the time-domain autocorrelation on one wavefront
     const bool yinFft = FFT && c.yinFft;              // (only the *_fft builds carry that path)
-    const bool specLpc = !yinFft && g.orderPitch < WAVE && nt >= 8 * WAVE;
+    const bool specLpc = COMMON || (!yinFft && g.orderPitch < WAVE && nt >= 8 * WAVE);
     // VP_YIN_XCORR: cross-correlation form of the difference function, certified (yin_pick) with the reference's
     // arithmetic as the fallback; needs the two-lags-per-lane layout on waves 1..4 and a free wave 5
     const int yNPairs = (g.tauMax + 1) >> 1, yWaves = (yNPairs + WAVE - 1) / WAVE;
-    const int xcCert = (c.yinCert != 0 && !yinFft && (g.C & 1) == 0 && yWaves <= 4 && nt == 8 * WAVE) ? c.yinCert : 0;
+    const int xcCert = (c.yinCert != 0 && (COMMON || (!yinFft && (g.C & 1) == 0 && yWaves <= 4 && nt == 8 * WAVE))) ? c.yinCert : 0;
     const bool levLate = xcCert != 0;                 // Levinson-Durbin at the top of the marks phase instead of beside the running sum
     const int acM = min(nt - 1 - tid, g.orderPitch);                         // the last wavefront's lag per lane
     // how much of the sum runs beside YIN (the cross-correlation form of YIN is shorter: less fits beside it)
@@ -1743,8 +1743,8 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     STAMPW_BEGIN();
     {
         const int base = g.toKeep - g.tauMax;
-        if (pendingCont >= 0 && (!pitch_can_overlap(g) || yinFft)) {      // no free wave: finish the old frame first
-            if (tid < WAVE) { pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
+        if (!COMMON && pendingCont >= 0 && (!pitch_can_overlap(g) || yinFft)) {      // no free wave: finish the old frame first
+            if (tid < WAVE) { pitch_iir_wave<LITE, FAST, COMMON>(g, L, pendingCont, hValid); pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s); }
             __syncthreads();
             pendingCont = -1;
         }
@@ -1804,7 +1804,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             const double E0 = P[g.F] - P[0];
             for (int k = tid; k < g.tauMax; k += nt) L.dY[k] = E0 + (P[k + g.F] - P[k]) - 2.0 * (zr[k] * invM);
             for (int m = tid; m <= g.orderPitch; m += nt) L.r[m] = (zi[m] * invM) / (double)g.F;
-        } else if ((g.C & 1) == 0) {
+        } else if (COMMON || (g.C & 1) == 0) {
             // TWO adjacent lags per lane (k = 2l, 2l+1): the lane slides one window of samples past
             // x[i], so each element costs one new LDS value for two lags, the two accumulation chains
             // interleave, and with the window base made even (see xsAll) every read is an aligned
@@ -1818,9 +1818,9 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             const int nPairs = (g.tauMax + 1) >> 1;
             const int wavesY = (nPairs + WAVE - 1) / WAVE;
             // waves 1..wavesY when that leaves wave 0 free for the previous frame's pending chunk
-            const int yw0 = (wavesY <= 6) ? 1 : 0;
+            const int yw0 = (COMMON || wavesY <= 6) ? 1 : 0;
             if (yw0 == 1 && pendingCont >= 0 && tid < WAVE) {
-                pitch_iir_wave<LITE, FAST>(g, L, pendingCont, hValid);
+                pitch_iir_wave<LITE, FAST, COMMON>(g, L, pendingCont, hValid);
                 pitch_fill_output_wave(g, c, d, L, pendingCont, pS, s);
             }
 #ifdef VP_DIAG_NO_YIN
@@ -2009,7 +2009,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         // follows at the top of the marks phase instead (levLate)
         if (!levLate) {
             const int order = g.orderPitch;
-            const bool z = (order < 16) ? levinson_row16(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
+            const bool z = (COMMON || order < 16) ? levinson_row16(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
                                         : levinson_wave(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
             if (tid == nt - 1) { L.ishare[2] = z ? 1 : 0; *L.lpcFlag = xcGen; }   // (a barrier follows before the FIR waves look)
             STAMPL(27);
@@ -2054,18 +2054,18 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             for (int j = 4 * (rank * WAVE + (tid & 63)); j < g.toKeep + g.F; j += 4 * nWork * WAVE)
                 fir4((const lds_f64 *)L.xs, a, order, j, g.toKeep + g.F, L.eF);
         }
-    } else if (tid >= nt - WAVE && g.orderPitch < WAVE) {
+    } else if (tid >= nt - WAVE && (COMMON || g.orderPitch < WAVE)) {
         // meanwhile, on the last wavefront (FFT mode: Levinson-Durbin first, the autocorrelation came late) ...
         if (!specLpc || levLate) {
             STAMPL_BEGIN();
-            const bool z = (g.orderPitch < 16) ? levinson_row16(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps)
+            const bool z = (COMMON || g.orderPitch < 16) ? levinson_row16(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps)
                                                : levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);
             if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
             __threadfence_block();
             if (tid == nt - 1) __hip_atomic_store(L.lpcFlag, xcGen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the FIR waves may go
             STAMPL(27);
         }
-        if ((g.C & 63) == 0) {
+        if (COMMON || (g.C & 63) == 0) {
             // ... the impulse response of the new 1/A(z) for the block-form IIR (cum[] is dead after
             // the normalisation; layout as in pitch_iir_wave)
             lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
@@ -2078,7 +2078,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     __syncthreads();
     STAMP(d, 4);
     if (st->nAn != 0) {
-        if (g.orderPitch < WAVE) {                                           // coefficients are ready: adopt them (:233)
+        if (COMMON || g.orderPitch < WAVE) {                                 // coefficients are ready: adopt them (:233)
             const int ncopy = L.ishare[2] ? VP_ORDER_MAX + 1 : g.orderPitch + 1;
             for (int i = tid; i < ncopy; i += nt) st->a[i] = L.aPrev[i];
         } else if (tid < WAVE)
@@ -2110,7 +2110,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     return 1;
 }
 
-template <bool LITE, bool FAST, bool MULTI, bool FFT>
+template <bool LITE, bool FAST, bool MULTI, bool FFT, bool COMMON>
 __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in0,
                                                   float *__restrict__ out0, double *smem)
 {
@@ -2181,7 +2181,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         for (int i = tid; i < g.eLen; i += nt) L.eF[i] = ge[i];
         for (int i = done + tid; i < g.F; i += nt) L.oE[i] = go[i];
         for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) L.yF[i] = gy[i];
-        if ((g.C & 63) == 0 && g.orderPitch < WAVE) {        // the frame's impulse response (block-form IIR)
+        if (COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE)) {   // the frame's impulse response (block-form IIR)
             if (tid < WAVE) { L.cum[128 + tid] = 0.0; L.cum[128 + WAVE + tid] = d.hImp[(size_t)s * WAVE + tid]; }
         }
     }
@@ -2189,7 +2189,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     if (tid == 0) { L.ishare[3] = 0; *L.lpcFlag = 0; *L.psFlag = 0; }   // flags (generation counters): YIN prefix sums, LPC coefficients, grain table
     __syncthreads();
     const bool frameLive0 = (c.nChunk0 != 0) && (L.st->nAn != 0);
-    const bool hValid0 = frameLive0 && (g.C & 63) == 0 && g.orderPitch < WAVE;
+    const bool hValid0 = frameLive0 && (COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE));
 
     bool qValid = false, hValid = hValid0;
     int xcGenCtr = 0, psGen = 0;
@@ -2242,8 +2242,8 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 if (nChunk == g.cpf - 1) nChunk = 0;
                 if (nChunk != 0) break;
                 nC = 0;
-                mode = pitch_chunk_start_pre<LITE, FAST, FFT>(g, c, d, L, boff + pS, s, pendingCont, hValid, xcGenCtr);   // pS: output position only
-                hValid = (mode != 0) && (g.C & 63) == 0 && g.orderPitch < WAVE;    // computed there for the new coefficients
+                mode = pitch_chunk_start_pre<LITE, FAST, FFT, COMMON>(g, c, d, L, boff + pS, s, pendingCont, hValid, xcGenCtr);   // pS: output position only
+                hValid = (mode != 0) && (COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE));    // computed there for the new coefficients
             }
             if (sub == 1) qValid = false;                 // a new frame: new beta / period
             if (mode == 2) {
@@ -2254,7 +2254,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
                 // the exact recursion keeps its history while it runs)
                 const bool ahead = qValid && nC + 1 <= g.cpf - 1 && step + 1 < nSteps && (step + 1) / g.xsSteps == step / g.xsSteps &&
                                    nt >= 2 * WAVE && g.tauMax + 1 >= 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2;
-                pitch_iir<LITE, FAST>(g, d, L, nC, hValid, ahead, (const lds_f64 *)(xsAll + ((step + 1) % g.xsSteps) * g.C), pS + g.C, psGen);
+                pitch_iir<LITE, FAST, COMMON>(g, d, L, nC, hValid, ahead, (const lds_f64 *)(xsAll + ((step + 1) % g.xsSteps) * g.C), pS + g.C, psGen);
                 preDone = ahead;
             } else
                 preDone = false;
@@ -2282,7 +2282,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         for (int i = tid; i < g.eLen; i += nt) ge[i] = L.eF[i];
         for (int i = done + tid; i < g.F; i += nt) go[i] = L.oE[i];
         for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) gy[i] = L.yF[i];
-        if ((g.C & 63) == 0 && g.orderPitch < WAVE && tid < WAVE) d.hImp[(size_t)s * WAVE + tid] = L.cum[128 + WAVE + tid];
+        if ((COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE)) && tid < WAVE) d.hImp[(size_t)s * WAVE + tid] = L.cum[128 + WAVE + tid];
     }
     STAMP(d, 11);
     if (c.fuseEmit) {
@@ -2302,7 +2302,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
 __global__ __launch_bounds__(512) void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, false, false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false, false, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2311,7 +2311,27 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast(VpGeom g, VpCall c, VpDev
                                                        float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, true, false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, true, false, false, false>(g, c, d, in, out, smem);
+}
+#endif
+
+// The COMMON-CASE builds of the two above: chunk a multiple of 64 samples, lpcPitch <= 15, tauMax <= 512 (any sample rate
+// up to 51.2 kHz with the plugin's own geometry).  Every alternative the general builds keep for other geometries and
+// orders (one-lag YIN, LDS-form block IIR, general Levinson-Durbin, the wave-0 fallback orders, ...) is compiled out:
+// code a launch never executes still costs it (section 4.2.1).  The host picks them whenever the handle qualifies.
+#if VP_TU_HAS(2)
+__global__ __launch_bounds__(512) void vp_k_pitch_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, false, false, false, true>(g, c, d, in, out, smem);
+}
+#endif
+#if VP_TU_HAS(3)
+__global__ __launch_bounds__(512) void vp_k_pitch_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                         float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, true, false, false, true>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2321,7 +2341,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch_multi(VpGeom g, VpCall c, VpDe
                                                         float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, false, true, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false, true, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2330,7 +2350,7 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c,
                                                              float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, true, true, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, true, true, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2339,14 +2359,14 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c,
 __global__ __launch_bounds__(512) void vp_k_pitch_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, false, false, true>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, false, false, true, false>(g, c, d, in, out, smem);
 }
 
 __global__ __launch_bounds__(512) void vp_k_pitch_fast_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
                                                            float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<false, true, false, true>(g, c, d, in, out, smem);
+    pitch_kernel_body<false, true, false, true, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2358,7 +2378,7 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite(VpGeom g, VpCall c, Vp
                                                            float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true, false, false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, false, false, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
@@ -2367,7 +2387,7 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall 
                                                                 float *__restrict__ out)
 {
     extern __shared__ double smem[];
-    pitch_kernel_body<true, true, false, false>(g, c, d, in, out, smem);
+    pitch_kernel_body<true, true, false, false, false>(g, c, d, in, out, smem);
 }
 #endif
 
