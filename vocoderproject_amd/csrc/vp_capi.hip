@@ -399,7 +399,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         const void *fns[] = {(const void *)vp_k_pitch, (const void *)vp_k_pitch_fast, (const void *)vp_k_pitch_multi,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
                              (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
-                             (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c,
+                             (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_vocoder};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -567,7 +567,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
             if (!lite && pitch_common(h)) k = cp.iirFast ? vp_k_pitch_fast_c : vp_k_pitch_c;    // the common-case builds
-            if (nBlocks > 1) k = cp.iirFast ? vp_k_pitch_fast_multi : vp_k_pitch_multi;       // never with `lite` or FFT (see the caller)
+            if (nBlocks > 1) k = cp.iirFast ? (pitch_common(h) ? vp_k_pitch_fast_multi_c : vp_k_pitch_fast_multi) : vp_k_pitch_multi;   // never with `lite` or FFT (see the caller)
             if (cp.yinFft) k = cp.iirFast ? vp_k_pitch_fast_fft : vp_k_pitch_fft;              // (never `lite`: pitch_lite())
             cp.ldsBytes = (int)lds;
             hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);

@@ -2335,6 +2335,15 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast_c(VpGeom g, VpCall c, VpD
 }
 #endif
 
+#if VP_TU_HAS(4)
+__global__ __launch_bounds__(512) void vp_k_pitch_fast_multi_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                               float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<false, true, true, false, true>(g, c, d, in, out, smem);
+}
+#endif
+
 // vp_process_blocks_device: the same two, looping over c.nBlocks consecutive blocks (state stays in LDS between them)
 #if VP_TU_HAS(4)
 __global__ __launch_bounds__(512) void vp_k_pitch_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
