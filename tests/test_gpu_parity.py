@@ -519,7 +519,7 @@ def test_pitch_kernel_build_selection():
     q.prepareToPlay(FS, 1024, 300)
     assert q.pitch_kernel_name() == "vp_k_pitch_lite"
     q.set_iir_mode("fast")
-    assert q.pitch_kernel_name() == "vp_k_pitch_lite_fast"
+    assert q.pitch_kernel_name() == "vp_k_pitch_lite_fast_c"
     q.set_yin_mode("fft")
     assert q.pitch_kernel_name() == "vp_k_pitch_fast_fft"        # the FFT accelerator has builds of its own (never the light one)
     q.set_iir_mode("exact")

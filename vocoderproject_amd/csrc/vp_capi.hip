@@ -96,6 +96,7 @@ extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
     const bool fast = h->iirMode == VP_IIR_FAST, lite = pitch_lite(h, fast, h->yinMode == VP_YIN_FFT);
     if (h->yinMode == VP_YIN_FFT && h->g.fftLog > 0) return fast ? "vp_k_pitch_fast_fft" : "vp_k_pitch_fft";
     if (!lite && pitch_common(h)) return fast ? "vp_k_pitch_fast_c" : "vp_k_pitch_c";
+    if (lite && fast && pitch_common(h)) return "vp_k_pitch_lite_fast_c";
     return lite ? (fast ? "vp_k_pitch_lite_fast" : "vp_k_pitch_lite") : (fast ? "vp_k_pitch_fast" : "vp_k_pitch");
 }
 
@@ -400,6 +401,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
                              (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
+                             (const void *)vp_k_pitch_lite_fast_c,
                              (const void *)vp_k_vocoder};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -567,6 +569,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
             auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
             if (!lite && pitch_common(h)) k = cp.iirFast ? vp_k_pitch_fast_c : vp_k_pitch_c;    // the common-case builds
+            if (lite && cp.iirFast && pitch_common(h)) k = vp_k_pitch_lite_fast_c;
             if (nBlocks > 1) k = cp.iirFast ? (pitch_common(h) ? vp_k_pitch_fast_multi_c : vp_k_pitch_fast_multi) : vp_k_pitch_multi;   // never with `lite` or FFT (see the caller)
             if (cp.yinFft) k = cp.iirFast ? vp_k_pitch_fast_fft : vp_k_pitch_fft;              // (never `lite`: pitch_lite())
             cp.ldsBytes = (int)lds;

@@ -15,6 +15,7 @@ __global__ void vp_k_pitch_fast_multi(VpGeom g, VpCall c, VpDev d, const float *
 __global__ void vp_k_pitch_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast_multi_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_lite_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);

@@ -1460,7 +1460,7 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
 #ifdef VP_DIAG_NO_REGS_IIR
         if (false)
 #else
-        if (COMMON || (!LITE && order <= 16))
+        if (!LITE && (COMMON || order <= 16))
 #endif
             iir_block_wave_regs((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, shift > 0, hpad);
         else
@@ -2360,6 +2360,16 @@ __global__ __launch_bounds__(512) void vp_k_pitch_fast_multi(VpGeom g, VpCall c,
 {
     extern __shared__ double smem[];
     pitch_kernel_body<false, true, true, false, false>(g, c, d, in, out, smem);
+}
+#endif
+
+#if VP_TU_HAS(5)
+// common-case build of the register-light FAST kernel (large batches)
+__global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in,
+                                                                  float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    pitch_kernel_body<true, true, false, false, true>(g, c, d, in, out, smem);
 }
 #endif
 
