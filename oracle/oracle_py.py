@@ -82,6 +82,11 @@ def lib():
         L.vpo_yin_temp_linear.argtypes = [dp, C.c_int, C.c_int, dp]
         L.vpo_yin_pick.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double]
         L.vpo_kat_pitch_marks.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]
+        L.vpo_kat_pitch_marks_seq.argtypes = [dp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double,
+                                               C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.vpo_kat_marks_seq.argtypes = [dp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int), dp]
         L.vpo_gain_to_db.argtypes = [C.c_double]
         L.vpo_gain_to_db.restype = C.c_double
         L.vpo_db_to_gain_f.argtypes = [C.c_float]
@@ -268,3 +273,38 @@ def kat_pitch_marks(x, period, F=1024, H=768, fs=44100.0):
     if n < 0:
         raise RuntimeError(f"kat_pitch_marks rc={n}")
     return list(m[:n])
+
+
+def kat_pitch_marks_seq(x, periods, F=1024, H=768, fs=44100.0):
+    """Consecutive frames through pitchMarks with the tracker state rolled as yin() does; periods[f] == 0 = unvoiced."""
+    x = np.ascontiguousarray(x, np.float64)
+    nf = len(periods)
+    assert x.size >= F + (nf - 1) * H
+    per = (C.c_int * nf)(*[int(p) for p in periods])
+    m = (C.c_int * (MARK_CAP * nf))()
+    cnt = (C.c_int * nf)()
+    rc = lib().vpo_kat_pitch_marks_seq(_dp(x), nf, per, F, H, fs, m, cnt)
+    if rc:
+        raise RuntimeError(f"kat_pitch_marks_seq rc={rc}")
+    return [list(m[f * MARK_CAP: f * MARK_CAP + cnt[f]]) for f in range(nf)]
+
+
+def kat_marks_seq(x, periods, F=1024, H=768, fs=44100.0):
+    """As kat_pitch_marks_seq plus placeStMarks after every frame (key = chromatic):
+    returns (anMarks per frame, stMarks per frame, periodNew per frame, beta per frame)."""
+    x = np.ascontiguousarray(x, np.float64)
+    nf = len(periods)
+    assert x.size >= F + (nf - 1) * H
+    per = (C.c_int * nf)(*[int(p) for p in periods])
+    m = (C.c_int * (MARK_CAP * nf))()
+    cnt = (C.c_int * nf)()
+    sm = (C.c_int * (MARK_CAP * nf))()
+    scnt = (C.c_int * nf)()
+    pn = (C.c_int * nf)()
+    beta = np.zeros(nf)
+    rc = lib().vpo_kat_marks_seq(_dp(x), nf, per, F, H, fs, m, cnt, sm, scnt, pn, _dp(beta))
+    if rc:
+        raise RuntimeError(f"kat_marks_seq rc={rc}")
+    an = [list(m[f * MARK_CAP: f * MARK_CAP + cnt[f]]) for f in range(nf)]
+    st = [list(sm[f * MARK_CAP: f * MARK_CAP + scnt[f]]) for f in range(nf)]
+    return an, st, list(pn), beta

@@ -1062,6 +1062,49 @@ int vpo_kat_pitch_marks(const double *x, int F, int H, double fs, int period, in
     return n;
 }
 
+/* A run of consecutive pitch frames through pitchMarks (:455-567) with the tracker state rolled the way yin()
+ * rolls it (:413-420): periods[f] > 0 = voiced frame with that period, 0 = unvoiced.  x holds F + (nFrames-1)*H
+ * samples; frame f is x[f*H .. f*H+F).  marksOut is [nFrames][VPO_MARK_CAP], countsOut [nFrames]. */
+int vpo_kat_marks_seq(const double *x, int nFrames, const int *periods, int F, int H, double fs, int *marksOut, int *countsOut,
+                      int *stMarksOut, int *stCountsOut, int *periodNewOut, double *betaOut);
+int vpo_kat_pitch_marks_seq(const double *x, int nFrames, const int *periods, int F, int H, double fs, int *marksOut, int *countsOut)
+{
+    return vpo_kat_marks_seq(x, nFrames, periods, F, H, fs, marksOut, countsOut, NULL, NULL, NULL, NULL);
+}
+
+/* ... and, when stMarksOut is given, placeStMarks (:573-658) after every pitchMarks, key = the default (chromatic). */
+int vpo_kat_marks_seq(const double *x, int nFrames, const int *periods, int F, int H, double fs, int *marksOut, int *countsOut,
+                      int *stMarksOut, int *stCountsOut, int *periodNewOut, double *betaOut)
+{
+    vpo *o = vpo_create();
+    if (!o) return -1;
+    int rc = vpo_prepare_explicit(o, fs, F, F, H, 512, 128);
+    if (rc) { vpo_destroy(o); return rc; }
+    o->pStart = 0;
+    o->period = 0; o->pitch = 0; o->prevPitch = 0; o->prevPeriod = 0;
+    for (int f = 0; f < nFrames; f++) {
+        for (int i = 0; i < F; i++) o->voice[(o->currCounter + i) % o->inSize] = x[(size_t)f * H + i];
+        o->prevPeriod = o->period; o->prevPitch = o->pitch;                  /* :413-414 */
+        if (o->pitch > 1) { o->prevVoicedPeriod = o->period; o->prevVoicedPitch = o->pitch; }   /* :416-420 */
+        o->period = periods[f];
+        o->pitch = periods[f] > 0 ? fs / periods[f] : 0.0;
+        pitch_marks(o);
+        int n = o->anMarks.n;
+        countsOut[f] = n;
+        memcpy(marksOut + (size_t)f * VPO_MARK_CAP, o->anMarks.v, (size_t)(n < VPO_MARK_CAP ? n : VPO_MARK_CAP) * sizeof(int));
+        if (stMarksOut) {
+            place_st_marks(o);
+            n = o->stMarks.n;
+            stCountsOut[f] = n;
+            memcpy(stMarksOut + (size_t)f * VPO_MARK_CAP, o->stMarks.v, (size_t)(n < VPO_MARK_CAP ? n : VPO_MARK_CAP) * sizeof(int));
+            periodNewOut[f] = o->periodNew;
+            betaOut[f] = o->beta;
+        }
+    }
+    vpo_destroy(o);
+    return 0;
+}
+
 int vpo_get_geometry(const vpo *o, int out[12])
 {
     out[0] = o->N; out[1] = o->F; out[2] = o->H; out[3] = o->C; out[4] = o->W; out[5] = o->h;

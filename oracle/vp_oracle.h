@@ -12,14 +12,18 @@
  *   reference is UNBUILDABLE here.  The reference has no tests, fixtures or golden vectors.
  *     - pinned (tests/golden/methods_vectors.npz, generated from the reference's own
  *       Notebook/methods.py in the build container): biased autocorrelation, Levinson-Durbin,
- *       YIN difference function + threshold walk, first-frame analysis pitch marks,
- *       sine window, chromatic note table.
+ *       YIN difference function + threshold walk, analysis pitch marks (first voiced frame
+ *       and runs of frames: continuation through the overlap, unvoiced extrapolation, restart),
+ *       synthesis pitch marks over the same runs (beta from the note table, new period,
+ *       continuity rules), the PSOLA Hann(2T+1) window, sine window, chromatic note table.
  *     - pinned (SURVEY.md Appendix A / section 3.1 known answers recorded from a survey-session run of the
  *       compiled reference): Notes::getClosestFreq KATs, prepareToPlay geometry (latency,
  *       inSize, outSize, tauMax at 44.1 kHz and 48 kHz), "ch2 returns 0".
- *     - PARITY UNPINNED: end-to-end processBlock() output, the pitch-mark state machine beyond
- *       the first voiced frame, PSOLA, and the JUCE arithmetic surface (getRMSLevel, Decibels,
- *       WindowingFunction hann), which is restated from JUCE 5.4.x documented semantics.
+ *     - PARITY UNPINNED: end-to-end processBlock() output, the mark branches methods.py does not
+ *       share with the plugin (voiced->voiced without marks in the overlap, getClosestAnMarkIdx),
+ *       PSOLA grain placement/interpolation (methods.pitch_shift works per frame, the plugin per
+ *       chunk), and the rest of the JUCE arithmetic surface (getRMSLevel, Decibels), which is
+ *       restated from JUCE 5.4.x documented semantics.
  *
  * Every function cites the reference file:line it restates (paths relative to
  * /root/reference/Source/).
@@ -97,6 +101,9 @@ void vpo_yin_temp_linear(const double *x, int frameLen, int tauMax, double *yinT
 int vpo_yin_pick(const double *yinTemp, int tauMax, double fS, double fMax, double yinTol);
 /* KAT hook: PitchProcess.cpp:455-567 for a frame following an unvoiced one; returns the mark count */
 int vpo_kat_pitch_marks(const double *x, int F, int H, double fs, int period, int *marksOut);
+int vpo_kat_marks_seq(const double *x, int nFrames, const int *periods, int F, int H, double fs, int *marksOut, int *countsOut,
+                      int *stMarksOut, int *stCountsOut, int *periodNewOut, double *betaOut);
+int vpo_kat_pitch_marks_seq(const double *x, int nFrames, const int *periods, int F, int H, double fs, int *marksOut, int *countsOut);
 /* JUCE Decibels */
 double vpo_gain_to_db(double gain);              /* gainToDecibels(double, -100) */
 float vpo_db_to_gain_f(float dB);                /* decibelsToGain(float, -59.0f) */

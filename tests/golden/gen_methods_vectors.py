@@ -11,8 +11,10 @@ different parametrisation -- SURVEY.md section 2 row 7 and section 8c):
   * biased_auto_corr          <-> LPC.cpp:44-97  (rectangular window)
   * levinson_durbin / lpc     <-> LPC.cpp:107-148
   * yin_algo                  <-> PitchProcess.cpp:350-448 (tau_max = round vs ceil: equal at 44.1 kHz/100 Hz)
-  * pitch_marks (first voiced frame after an unvoiced one: search right + left)
+  * pitch_marks (first voiced frame after an unvoiced one: search right + left; runs of frames: continuation
+    through the overlap's marks, unvoiced extrapolation, restart)
                               <-> PitchProcess.cpp:455-567
+  * hann(2T+1) as pitch_shift uses it <-> PitchProcess.cpp:878-882 (JUCE symmetric Hann)
   * create_window('sine')     <-> VocoderProcess.cpp:95-135 (np.pi vs the literal 3.14159265)
   * build_notes_vector('chromatic') <-> Notes.cpp:43-70
 """
@@ -96,6 +98,71 @@ def main():
         out[f"pm{ci}_period"] = np.int64(int(FS / pitch))     # the T methods.pitch_marks itself derives
         pm_cases.append(f0)
     out["pm_cases"] = np.array(pm_cases)
+
+    # ---- analysis pitch marks over RUNS of frames: voiced->voiced continuation through the marks of the overlap,
+    #      voiced->unvoiced periodic extrapolation (with and without marks in the overlap), unvoiced->voiced restart
+    #      (search right + left).  The tracker state rolls as in the notebook's driver loop: prev_marks = last marks,
+    #      prev_pitch = last frame's pitch, prev_voiced_pitch = last voiced pitch.  (The voiced->voiced branch WITHOUT
+    #      marks in the overlap is left out: methods.pitch_marks returns the arg-extremum relative to the search
+    #      slice there, the plugin an absolute index.)
+    H = 768
+    seqs = [(130.0, "VVVUUVVUV"), (233.0, "VVUUUVVVU"), (300.0, "VUVVUUVVV"), (180.0, "VVUUVVV"), (420.0, "VVVUVVUUV")]
+    for si, (f0, pat) in enumerate(seqs):
+        nf = len(pat)
+        x = voiced(rng, w_len + (nf - 1) * H, f0, noise=0.0005)
+        T = int(FS / f0)
+        pitch = FS / T
+        assert int(FS / pitch) == T                       # methods derives T back from the pitch
+        prev_marks = np.array([], dtype=int)
+        prev_st = np.array([], dtype=int)
+        prev_pitch, prev_voiced = 0.0, 100.0
+        periods, all_marks, all_st, betas = [], [], [], []
+        # synthesis marks (methods.synthesis_pitch_marks <-> placeStMarks, PitchProcess.cpp:573-658) with beta = nearest
+        # chromatic note / pitch, the notes being the reference module's own table.  methods takes T_new =
+        # int(fs / (beta pitch)), the plugin round(period / beta): the cases keep frac(fs / note) < 0.5 where the two
+        # agree; on unvoiced frames the plugin ignores beta (periodNew = prevVoicedPeriod), so methods gets beta = 1.
+        notes_tab, _ = M.build_notes_vector("chromatic", n_oct=4)
+        closest = float(notes_tab[np.argmin(np.abs(notes_tab - pitch))])
+        assert (FS / closest) % 1.0 < 0.5, (f0, FS / closest)
+        for f, c in enumerate(pat):
+            cur = pitch if c == "V" else 0.0
+            xf = x[f * H: f * H + w_len]
+            if cur > 10 and prev_pitch > 10:
+                assert np.sum(prev_marks - H >= 0) > 0, "voiced->voiced without overlap marks: not comparable"
+            marks = np.asarray(M.pitch_marks(xf, cur, prev_marks, prev_pitch, prev_voiced, w_len, H, FS, 0.94, valley=True),
+                               dtype=np.int64)
+            all_marks.append(marks)
+            periods.append(T if c == "V" else 0)
+            beta = closest / pitch if cur > 10 else 1.0
+            if marks.size == 0:
+                st = np.array([], dtype=np.int64)             # placeStMarks returns with no marks (:580-581); methods would index an_marks[0]
+            else:
+                st = np.asarray(M.synthesis_pitch_marks(cur, prev_pitch, prev_voiced, marks, prev_st, beta, w_len, H, FS),
+                                dtype=np.int64)
+                if cur > 10 and not prev_pitch > 10:
+                    # restart: methods also lays marks to the LEFT of an_marks[0] (arange(-3, ...)), the plugin starts at it
+                    assert marks[0] - int(FS / (beta * cur)) < 0, "restart case not comparable"
+            all_st.append(st)
+            betas.append(beta)
+            prev_st = st
+            prev_marks = marks
+            prev_pitch = cur
+            if cur > 10:
+                prev_voiced = cur
+        out[f"pmseq{si}_x"] = x
+        out[f"pmseq{si}_periods"] = np.array(periods, dtype=np.int64)
+        out[f"pmseq{si}_counts"] = np.array([len(m) for m in all_marks], dtype=np.int64)
+        out[f"pmseq{si}_marks"] = np.concatenate(all_marks) if all_marks else np.array([], dtype=np.int64)
+        out[f"pmseq{si}_st_counts"] = np.array([len(m) for m in all_st], dtype=np.int64)
+        out[f"pmseq{si}_st_marks"] = np.concatenate(all_st)
+        out[f"pmseq{si}_beta"] = np.array(betas)
+    out["pmseq_n"] = np.int64(len(seqs))
+
+    # ---- the PSOLA grain window: methods.pitch_shift takes hann(2T+1) (methods.py:401, scipy's symmetric Hann, the
+    #      function object the reference module itself imported) <-> fillPsolaWindow's JUCE symmetric Hann
+    #      (PitchProcess.cpp:878-882)
+    for T in (55, 292, 441):
+        out[f"hann_{2 * T + 1}"] = np.asarray(M.hann(2 * T + 1), dtype=np.float64)
 
     # ---- windows and note table ----------------------------------------------------------------------------------
     for W, ov in [(512, 0.75), (1024, 0.75), (2048, 0.75), (556, 0.75), (512, 0.5)]:

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -391,6 +392,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     if (h->pitchLds > ldsMax) { h->lastError = "pitch frame does not fit LDS"; return VP_ERR_GEOMETRY; }
     int nw = 8;
     while (nw > 1 && vp_voc_lds_bytes(W, nw) > ldsMax) nw--;
+    if (const char *e = getenv("VP_VOC_WAVES")) { int v = atoi(e); if (v >= 1 && v < nw) nw = v; }    // diagnostic override
     if (vp_voc_lds_bytes(W, nw) > ldsMax) { h->lastError = "vocoder window does not fit LDS"; return VP_ERR_GEOMETRY; }
     h->vocWaves = nw;
     h->vocLds = vp_voc_lds_bytes(W, nw);
