@@ -143,6 +143,9 @@ def main():
                          "decisions as 'direct' (the reference's arithmetic) and falls back to it otherwise: same output bits")
     ap.add_argument("--blocks-per-step", type=int, default=1,
                     help="host blocks of N samples handed over per step (vp_process_blocks_device; one launch in pitch mode)")
+    ap.add_argument("--shift", type=float, default=None,
+                    help="extension (no reference counterpart): fixed pitch-shift interval in semitones, +x on even and -x "
+                         "on odd streams (vp_set_pitch_shift), instead of the correction to the key's nearest note")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -170,6 +173,13 @@ def main():
     p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"))
     p.prepareToPlay(FS, N, S)
     p.set_yin_mode(args.yin)
+
+    def set_shift(semi):
+        for s_ in range(S):
+            p.setPitchShift(semi if s_ % 2 == 0 else -semi, on=True, stream=s_)
+
+    if args.shift is not None and mode != "voc":
+        set_shift(args.shift)
 
     # synthetic inputs in HBM: [U][S][3][N], stream ids unique across ranks
     U = UNIQUE_BLOCKS
@@ -242,6 +252,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)          # the only collective: a checksum of the outputs
     dt, dt_other, dt_mb = float(tt[0].item()), float(tt[1].item()), float(tt[2].item())
+    # a third secondary figure, AFTER the headline region: BASELINE configs[1]'s "+-12-semitone pitch shift" (fixed
+    # interval, +12 on even and -12 on odd streams; extension without a reference counterpart, parity GPU <-> oracle)
+    dt_shift = float("nan")
+    if not args.single_mode and args.shift is None and mode != "voc" and BPS == 1:
+        set_shift(12.0)
+        dt_shift, _ = timed(args.iir, k2, max(4, args.warmup // 2))
+        ts = torch.tensor([dt_shift], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        dt_shift = float(ts[0].item())
 
     frames_per_step_gpu = S * N * BPS // HOP
     total_frames = frames_per_step_gpu * args.steps * n_gpus
@@ -263,7 +283,7 @@ def main():
             "config": {"workload": f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
                                    f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
-                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "frames_per_step": frames_per_step_gpu * n_gpus,
+                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "frames_per_step": frames_per_step_gpu * n_gpus,
                        "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -276,6 +296,7 @@ def main():
             "checksum": float(chk.item()),
             f"value_{other}_mode": (frames_per_step_gpu * k2 * n_gpus / dt_other) if dt_other == dt_other else None,
             "value_8_blocks_per_call": ((S * N * MB // HOP) * k3 * n_gpus / dt_mb) if dt_mb == dt_mb else None,
+            "value_pm12_semitone_shift": (frames_per_step_gpu * k2 * n_gpus / dt_shift) if dt_shift == dt_shift else None,
         }
         if not args.single_mode:
             out["stft_kernel"] = stft_figure(dev, S)

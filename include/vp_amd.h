@@ -86,6 +86,15 @@ int vp_set_stream_params(vp_handle *h, int stream, const vp_params *p);
 int vp_get_stream_params(const vp_handle *h, int stream, vp_params *p);
 void vp_default_params(vp_params *p);
 
+/* EXTENSION (no reference counterpart; BASELINE configs[1] "+-12-semitone pitch shift"): a fixed interval instead of
+ * the correction to the key's nearest note.  placeStMarks (PitchProcess.cpp:593-598) then takes
+ * beta = 2^(semitones/12) (host libm) in place of closestFreq/pitch; everything else on the path is unchanged.
+ * stream = -1 sets every stream.  After prepare; takes effect at the next analysed frame; a new prepare switches it
+ * off.  |semitones| <= 12 (VP_ERR_INVALID_ARG); VP_ERR_GEOMETRY when an upward shift would need more synthesis marks
+ * per frame than VP_MARK_CAP (F / round(floor(fs/fMax) / beta) + 2). */
+int vp_set_pitch_shift(vp_handle *h, int stream, int on, double semitones);
+int vp_get_pitch_shift(const vp_handle *h, int stream, int *on, double *semitones);
+
 /* VocoderAudioProcessor::prepareToPlay(sampleRate, samplesPerBlock) (PluginProcessor.cpp:144-184)
  * for n_streams instances: derives the vocoder/pitch geometry from the sample rate (:159-170),
  * allocates and zeroes all per-stream state in HBM. */

@@ -68,6 +68,8 @@ public:
     }
     const vp_params &parameters() const { return p_; }
     // one stream's own treeState value (after prepare; pitchBool/vocBool/lpcPitch stay per handle)
+    // extension: fixed interval (+-12 semitones) instead of the key's nearest note; stream = -1: all streams
+    void setPitchShift(double semitones, bool on = true, int stream = -1) { check(vp_set_pitch_shift(h_, stream, on ? 1 : 0, semitones), "setPitchShift"); }
     void setStreamParameter(int stream, const char *id, float v)
     {
         vp_params q;

@@ -61,6 +61,7 @@ def lib():
         L.vpo_destroy.argtypes = [C.c_void_p]
         L.vpo_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_float]
         L.vpo_get_param.argtypes = [C.c_void_p, C.c_char_p]
+        L.vpo_set_pitch_shift.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.vpo_get_param.restype = C.c_float
         L.vpo_prepare_to_play.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.vpo_prepare_explicit.argtypes = [C.c_void_p, C.c_double] + [C.c_int] * 5
@@ -123,6 +124,10 @@ class OracleStream:
         rc = self.L.vpo_set_param(self.h, pid.encode(), float(value))
         if rc:
             raise ValueError(f"bad parameter {pid}={value}")
+
+    def set_pitch_shift(self, semitones, on=True):
+        if self.L.vpo_set_pitch_shift(self.h, int(bool(on)), float(semitones)):
+            raise ValueError(f"bad pitch shift {semitones}")
 
     def get_param(self, pid):
         return self.L.vpo_get_param(self.h, pid.encode())

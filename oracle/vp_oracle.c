@@ -91,6 +91,7 @@ struct vpo {
     double fMin, fMax, delta, yinTol, overlap;
     int key;
     int period, prevPeriod, prevVoicedPeriod, periodNew;
+    int shiftOn; double shiftBeta;              /* extension: fixed shift factor 2^(semitones/12) instead of the key's note */
     double pitch, prevPitch, prevVoicedPitch, closestFreq, prevClosestFreq, beta;
     int stMarkIdx, nAnMarksOv, nStMarksOv;
     double *yinTemp;               /* tauMax (+1 guard slot, see yin()) */
@@ -466,6 +467,7 @@ static int pitch_prepare(vpo *o, double fS, double fMin, double fMax, int frameL
     o->overlap = ((double)(frameLen - hop)) / ((double)frameLen);
     o->delta = 0.94; o->pitch = 0; o->prevPitch = 0; o->period = 0; o->periodNew = 0;
     o->prevVoicedPeriod = 0; o->prevPeriod = 0; o->beta = 1; o->yinTol = 0.25;
+    o->shiftOn = 0; o->shiftBeta = 1;                                      /* extension: off after every prepare */
     o->prevVoicedPitch = 0; o->closestFreq = 0; o->prevClosestFreq = 0;   /* uninitialised in the reference */
     o->stMarkIdx = 0; o->nAnMarksOv = 0; o->nStMarksOv = 0;
     o->pStart = 0; o->bufferIdxMax = 0; o->silenceDb = silenceDb;
@@ -696,6 +698,10 @@ static void place_st_marks(vpo *o)                                          /* :
     if (o->pitch > 1) {
         o->closestFreq = notes_get_closest(o, o->pitch, o->key);
         o->beta = o->closestFreq / o->pitch;
+        if (o->shiftOn) {                      /* extension, no reference counterpart: fixed interval (vpo_set_pitch_shift) */
+            o->beta = o->shiftBeta;
+            o->closestFreq = o->beta * o->pitch;
+        }
         o->periodNew = (int)round(o->period / o->beta);
     } else {
         o->closestFreq = 0;
@@ -970,6 +976,16 @@ static float *param_slot(vpo *o, const char *id, float *lo, float *hi)
     for (unsigned i = 0; i < sizeof t / sizeof t[0]; i++)
         if (strcmp(t[i].id, id) == 0) { *lo = t[i].lo; *hi = t[i].hi; return t[i].p; }
     return NULL;
+}
+
+/* Extension used by BASELINE configs[1] ("+-12-semitone pitch shift"): placeStMarks takes beta = 2^(semitones/12)
+ * instead of closestFreq/pitch (:596-598).  The plugin has no such parameter: parity for it is GPU <-> this file only. */
+int vpo_set_pitch_shift(vpo *o, int on, double semitones)
+{
+    if (!(semitones >= -12.0 && semitones <= 12.0)) return -1;
+    o->shiftOn = on ? 1 : 0;
+    o->shiftBeta = pow(2.0, semitones / 12.0);
+    return 0;
 }
 
 int vpo_set_param(vpo *o, const char *id, float value)

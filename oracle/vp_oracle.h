@@ -60,6 +60,8 @@ void vpo_destroy(vpo *o);
  * Returns 0, or -1 for an unknown id / out-of-range value. */
 int vpo_set_param(vpo *o, const char *id, float value);
 float vpo_get_param(const vpo *o, const char *id);
+/* extension (no reference counterpart): fixed pitch-shift interval instead of the key's nearest note */
+int vpo_set_pitch_shift(vpo *o, int on, double semitones);
 int vpo_prepare_to_play(vpo *o, double sampleRate, int samplesPerBlock);   /* :144-184 */
 /* Explicit geometry (restates :172-183 with explicit sizes).  Returns 0 or a negative
  * code when the reference would assert (overlap not 0.5/0.75, F % (F-H) != 0, ...). */

@@ -778,3 +778,100 @@ def test_exact_iir_every_small_order(order):
         p = BatchVocoderProcessor(**params)
         p.prepareToPlay(FS, N, S)
         _assert_equal(p.run(x), _oracle_run(x, N, params), f"lpcPitch={order} N={N}")
+
+
+# ---- extension: fixed pitch-shift interval (BASELINE configs[1] "+-12-semitone pitch shift") -----------------------------
+
+@pytest.mark.parametrize("mode", ["pitch", "both"])
+def test_fixed_pitch_shift_extension_bit_exact(mode):
+    """vp_set_pitch_shift: beta = 2^(semitones/12) in placeStMarks instead of the key's nearest note, per stream, set
+    before and between blocks.  No reference counterpart: the bar is GPU == oracle (the oracle's own version of the
+    extension is checked musically in tests/test_oracle_behaviour.py), bit-exact like everything else."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    S, N, B = 7, 1024, 26
+    x = np.concatenate([_streams(4, N * B), _edge_streams(N * B)[:3]])
+    shifts = [12.0, -12.0, 7.0, -5.0, None, 0.37, -12.0]
+    later = {9: (4, 3.0), 14: (0, None), 18: (6, 12.0)}
+    params = dict(vocBool=0) if mode == "pitch" else dict()
+    p = BatchVocoderProcessor(**params)
+    with pytest.raises(VpError):
+        p.setPitchShift(3.0)                                         # before prepare
+    p.prepareToPlay(FS, N, S)
+    with pytest.raises(VpError):
+        p.setPitchShift(12.5)
+    with pytest.raises(VpError):
+        p.setPitchShift(1.0, stream=S)
+    os_ = []
+    for s_ in range(S):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(FS, N)
+        if shifts[s_] is not None:
+            p.setPitchShift(shifts[s_], stream=s_)
+            o.set_pitch_shift(shifts[s_])
+        os_.append(o)
+    assert p.getPitchShift(0) == (True, 12.0) and p.getPitchShift(4)[0] is False
+    diff_from_plain = 0
+    plain = _oracle_run(x, N, params)
+    for b in range(B):
+        if b in later:
+            s_, v = later[b]
+            p.setPitchShift(v if v is not None else 0.0, on=v is not None, stream=s_)
+            os_[s_].set_pitch_shift(v if v is not None else 0.0, on=v is not None)
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        got = p.process(blk)
+        for s_ in range(S):
+            io = blk[s_].copy()
+            os_[s_].process_block(io)
+            _assert_equal(got[s_], io[:2], f"block {b} stream {s_} shift {shifts[s_]}")
+            diff_from_plain += int(np.any(io[:2] != plain[s_][:, b * N:(b + 1) * N]))
+    assert diff_from_plain > B                                       # the shift does something
+    ub = np.sum([o.ub_counters() for o in os_], axis=0)
+    assert list(p.ub_counters()) == list(ub)
+    # the tracker holds the fixed factor
+    st = p.pitch_state(1)
+    if st["period"] > 0:
+        assert st["beta"] == 0.5
+    # a new prepare switches the extension off
+    p.prepareToPlay(FS, N, S)
+    assert p.getPitchShift(0)[0] is False
+
+
+def test_fixed_pitch_shift_fast_modes_and_large_batch():
+    """The shift through the arithmetic modes bench.py runs (FAST IIR, certified cross-correlation YIN) and through the
+    register-light build for large batches: decisions identical to the exact default, samples within tolerance."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 260, 1024, 10                                           # > 256 streams: vp_k_pitch_lite*
+    x = np.tile(_streams(13, N * B), (20, 1, 1))
+    semis = [12.0 if s_ % 2 == 0 else -12.0 for s_ in range(S)]
+    outs, states = {}, {}
+    for tag, iir, yin in [("exact", "exact", "direct"), ("fast", "fast", "xcorr")]:
+        p = BatchVocoderProcessor(vocBool=0)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode(iir); p.set_yin_mode(yin)
+        for s_ in range(S):
+            p.setPitchShift(semis[s_], stream=s_)
+        outs[tag] = p.run(x)
+        states[tag] = [p.pitch_state(s_) for s_ in (0, 1, 14, 259)]
+    err = outs["fast"].astype(np.float64) - outs["exact"]
+    assert np.sqrt((err ** 2).mean()) < RMS_TOL
+    for a, b_ in zip(states["exact"], states["fast"]):
+        assert (a["period"], a["anMarks"], a["stMarks"], a["beta"]) == (b_["period"], b_["anMarks"], b_["stMarks"], b_["beta"])
+    # streams 0 and 26 carry the same input and the same shift: batch position must not matter
+    np.testing.assert_array_equal(outs["exact"][0], outs["exact"][26])
+    # against the oracle on a sample of streams
+    from oracle import oracle_py as O
+    for s_ in (0, 1, 259):
+        o = O.OracleStream(vocBool=0)
+        o.prepare_to_play(FS, N)
+        o.set_pitch_shift(semis[s_])
+        _assert_equal(outs["exact"][s_], o.run(x[s_]), f"stream {s_}")
+
+
+def test_fixed_pitch_shift_rejected_when_marks_would_not_fit():
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    p = BatchVocoderProcessor()
+    p.prepareExplicit(48000.0, 2048, 2, 2048, 1536, 2048, 512)        # 2048 / round(60 / 2) + 2 = 70 marks > 64
+    with pytest.raises(VpError):
+        p.setPitchShift(12.0)
+    p.setPitchShift(7.0)                                              # 2048 / 40 + 2 = 53: fine

@@ -101,3 +101,39 @@ def test_oracle_is_clean_under_asan_ubsan():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
+
+
+def _first_strong_lag(y, lo=40, hi=700):
+    y = y - y.mean()
+    ac = np.array([np.dot(y[:-k], y[k:]) for k in range(lo, hi)])
+    ac /= np.dot(y, y)
+    k = int(np.argmax(ac > 0.8 * ac.max()))
+    while k + 1 < ac.size and ac[k + 1] > ac[k]:
+        k += 1
+    return lo + k
+
+
+@pytest.mark.parametrize("semitones,ratio", [(12.0, 0.5), (-12.0, 2.0), (7.0, 2.0 ** (-7 / 12))])
+def test_fixed_pitch_shift_extension_moves_the_fundamental(semitones, ratio):
+    # Extension (no reference counterpart, BASELINE configs[1]): beta = 2^(semitones/12) instead of the key's note.
+    # A 147 Hz harmonic tone (period 300) must come out with its period scaled by 1/beta.
+    T, n = 300, 1024 * 40
+    t = np.arange(n)
+    v = sum(np.sin(2 * np.pi * h * t / T) / h for h in range(1, 9)) * 0.2
+    x = np.zeros((3, n), np.float32)
+    x[0] = v
+    o = O.OracleStream(vocBool=0)
+    o.prepare_to_play(FS, 1024)
+    o.set_pitch_shift(semitones)
+    y = o.run(x)[0]
+    got = _first_strong_lag(y[1024 * 10:].astype(np.float64))
+    assert abs(got - T * ratio) <= 0.02 * T * ratio + 1, (got, T * ratio)
+    with pytest.raises(ValueError):
+        o.set_pitch_shift(12.5)
+    o2 = O.OracleStream(vocBool=0)                       # switched off again: the plugin's own correction
+    o2.prepare_to_play(FS, 1024)
+    o2.set_pitch_shift(5.0)
+    o2.set_pitch_shift(0.0, on=False)
+    o3 = O.OracleStream(vocBool=0)
+    o3.prepare_to_play(FS, 1024)
+    np.testing.assert_array_equal(o2.run(x[:, :1024 * 8]), o3.run(x[:, :1024 * 8]))

@@ -40,6 +40,8 @@ struct vp_handle {
     // per-stream parameter overrides (vp_set_stream_params): host copy, device copy, upload pending
     std::vector<vp_params> sparams;             // [S] what each stream's treeState holds
     std::vector<VpStreamParams> spHost;         // [S] the same in kernel form (float gains applied), staging for the upload
+    std::vector<int> shiftOn;                   // [S] vp_set_pitch_shift: fixed interval instead of the key's nearest note
+    std::vector<double> shiftSemi, shiftBeta;   // [S]
     bool perStream = false, spDirty = false;    // any stream differs from `params` / device copy out of date
     struct EvPair { hipEvent_t a, b; int slot; };
     std::vector<EvPair> pending;
@@ -190,6 +192,38 @@ extern "C" int vp_set_stream_params(vp_handle *h, int stream, const vp_params *p
     h->sparams[stream] = *p;
     h->perStream = true;
     h->spDirty = true;
+    return VP_OK;
+}
+
+// Extension (BASELINE configs[1] "+-12-semitone pitch shift"; the plugin only corrects to the key's nearest note):
+// placeStMarks takes beta = 2^(semitones/12) instead of closestFreq/pitch (PitchProcess.cpp:596-598).
+extern "C" int vp_set_pitch_shift(vp_handle *h, int stream, int on, double semitones)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (stream < -1 || stream >= h->g.S) { h->lastError = "stream index out of range"; return VP_ERR_INVALID_ARG; }
+    if (!(semitones >= -12.0 && semitones <= 12.0)) { h->lastError = "pitch shift outside +-12 semitones"; return VP_ERR_INVALID_ARG; }
+    const double beta = pow(2.0, semitones / 12.0);
+    if (on) {
+        // the synthesis marks of a frame must fit the mark arrays: shortest period floor(fs/fMax), new period round(period/beta)
+        const int pNew = (int)round(h->g.tau0 / beta);
+        if (pNew < 1 || h->g.F / pNew + 2 > VP_MARKS) {
+            h->lastError = "pitch shift needs more synthesis marks per frame than the mark arrays hold";
+            return VP_ERR_GEOMETRY;
+        }
+    }
+    const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? h->g.S : stream + 1;
+    for (int i = lo; i < hi; i++) { h->shiftOn[i] = on ? 1 : 0; h->shiftSemi[i] = semitones; h->shiftBeta[i] = beta; }
+    h->spDirty = true;
+    return VP_OK;
+}
+
+extern "C" int vp_get_pitch_shift(const vp_handle *h, int stream, int *on, double *semitones)
+{
+    if (!h || !on || !semitones) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (stream < 0 || stream >= h->g.S) return VP_ERR_INVALID_ARG;
+    *on = h->shiftOn[stream]; *semitones = h->shiftSemi[stream];
     return VP_OK;
 }
 
@@ -461,6 +495,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     h->vStart = 0; h->pStart = 0; h->nChunk = 0;                             // VocoderProcess.cpp:39, PitchProcess.cpp:85,90
     h->sparams.assign((size_t)S, h->params);                                 // prepare starts every stream from the handle's set
     h->spHost.assign((size_t)S, VpStreamParams{});
+    h->shiftOn.assign((size_t)S, 0); h->shiftSemi.assign((size_t)S, 0.0); h->shiftBeta.assign((size_t)S, 1.0);
     h->perStream = false; h->spDirty = true;                                 // the fresh (zeroed) state needs them
     h->prepared = true;
     (void)hipDeviceSynchronize();
@@ -504,7 +539,7 @@ struct ProfScope {
 // float gains via decibelsToGain computed in float, switches of the dry paths (PluginProcessor.cpp:214-230)
 static void fill_stream_params(VpStreamParams &o, const vp_params &P)
 {
-    o.orderVoice = P.lpcVoice; o.orderSynth = P.lpcSynth; o.key = P.keyPitch; o.pad = 0;
+    o.orderVoice = P.lpcVoice; o.orderSynth = P.lpcSynth; o.key = P.keyPitch;
     o.dryOn = ((double)P.gainVoice > -59.0);                                 // PluginProcessor.cpp:226
     o.synthOn = ((double)P.gainSynth > -59.0);                               // :229
     o.gainPitch = (double)db_to_gain_f(P.gainPitch);
@@ -530,7 +565,10 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     if (h->spDirty) {
         // orders, key, gains and the dry-path switches travel in each stream's device state (VpPitchState::sp);
         // rewritten here, stream-ordered in front of this block's kernels, whenever a set call changed them
-        for (int i = 0; i < g.S; i++) fill_stream_params(h->spHost[i], h->sparams[i]);
+        for (int i = 0; i < g.S; i++) {
+            fill_stream_params(h->spHost[i], h->sparams[i]);
+            h->spHost[i].shiftOn = h->shiftOn[i]; h->spHost[i].shiftBeta = h->shiftBeta[i];
+        }
         HIPCHK(h, hipMemcpy2DAsync(&h->d.pitch[0].sp, sizeof(VpPitchState), h->spHost.data(), sizeof(VpStreamParams),
                                    sizeof(VpStreamParams), (size_t)g.S, hipMemcpyHostToDevice, st));
         h->spDirty = false;

@@ -54,8 +54,10 @@ struct VpCall {
 // the stream's device state -- the pitch kernel stages that in LDS anyway -- and are rewritten by the host whenever
 // vp_set_params / vp_set_stream_params changed them (stream-ordered, in front of the block's kernels).
 struct VpStreamParams {
-    int orderVoice, orderSynth, key, dryOn, synthOn, pad;
+    int orderVoice, orderSynth, key, dryOn, synthOn;
+    int shiftOn;                                       // extension (no reference counterpart): fixed shift factor instead of the key's note
     double gainPitch, gainVoc, gainVoice, gainSynth;   // (double) of the float gains
+    double shiftBeta;                                  // 2^(semitones/12), host libm
 };
 
 struct VpPitchState {

@@ -1127,6 +1127,10 @@ __device__ __forceinline__ void place_st_marks(const VpGeom &g, const VpCall &c,
         const int key = st->sp.key;
         st->closestFreq = notes_closest(d.notes + (size_t)key * VP_NOTES_STRIDE, d.notesN[key], st->pitch);
         st->beta = st->closestFreq / st->pitch;
+        if (st->sp.shiftOn) {                       // vp_set_pitch_shift (extension): a fixed interval instead of the nearest note
+            st->beta = st->sp.shiftBeta;
+            st->closestFreq = st->beta * st->pitch;
+        }
         st->periodNew = (int)round(st->period / st->beta);
     } else {
         st->closestFreq = 0;

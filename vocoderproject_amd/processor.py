@@ -82,6 +82,9 @@ def load_library():
     if hasattr(L, "vp_set_stream_params"):            # absent only from older builds loaded through VP_AMD_LIB (tools/ab.sh)
         L.vp_set_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vp_get_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "vp_set_pitch_shift"):
+        L.vp_set_pitch_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+        L.vp_get_pitch_shift.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.vp_pitch_kernel_name.argtypes = [C.c_void_p]
     L.vp_pitch_kernel_name.restype = C.c_char_p
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
@@ -159,6 +162,16 @@ class BatchVocoderProcessor:
         self._chk(self.L.vp_get_stream_params(self.h, int(stream), C.byref(q)))
         setattr(q, pid, type(getattr(q, pid))(value))
         self._chk(self.L.vp_set_stream_params(self.h, int(stream), C.byref(q)))
+
+    def setPitchShift(self, semitones, on=True, stream=-1):
+        """Extension (no reference counterpart): shift by a fixed interval of +-12 semitones instead of correcting to
+        the key's nearest note; stream = -1 sets every stream of the batch."""
+        self._chk(self.L.vp_set_pitch_shift(self.h, int(stream), int(bool(on)), float(semitones)))
+
+    def getPitchShift(self, stream):
+        on, semi = C.c_int(), C.c_double()
+        self._chk(self.L.vp_get_pitch_shift(self.h, int(stream), C.byref(on), C.byref(semi)))
+        return bool(on.value), semi.value
 
     def getStreamParameter(self, stream, pid):
         q = VpParams()
