@@ -126,6 +126,9 @@ int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void 
  * enabled the blocks run in ONE launch (tracker state and the frame in flight stay on chip between them); other
  * plans are issued block by block.  Parameters are read once, at entry. */
 int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream);
+/* The same from HOST memory: in float [n_blocks][n_streams][3][N], out float [n_blocks][n_streams][2][N]; one upload,
+ * the blocks, one download, synchronises before returning (staging buffers grow on demand; VP_ERR_OOM). */
+int vp_process_blocks(vp_handle *h, const float *in, float *out, int n_blocks);
 
 /* Arithmetic of the two all-pole synthesis filters (VocoderProcess.cpp:277-286, PitchProcess.cpp:307-322).
  * VP_IIR_EXACT (default): the reference's summation order, output bit-identical to the CPU restatement.

@@ -108,6 +108,8 @@ public:
     {
         check(vp_process_blocks_device(h_, dIn, dOut, nBlocks, hipStream), "processBlocksDevice");
     }
+    // the same from host memory (one upload, the blocks, one download)
+    void processBlocks(const float *in, float *out, int nBlocks) { check(vp_process_blocks(h_, in, out, nBlocks), "processBlocks"); }
     int getLatencySamples() const { return vp_get_latency(h_); }                   // :183
     BufferView bufferView() const
     {

@@ -875,3 +875,65 @@ def test_fixed_pitch_shift_rejected_when_marks_would_not_fit():
     with pytest.raises(VpError):
         p.setPitchShift(12.0)
     p.setPitchShift(7.0)                                              # 2048 / 40 + 2 = 53: fine
+
+
+# ---- offline (file-to-file) front end: SURVEY.md section 8f item 4 -------------------------------------------------------
+
+def _oracle_offline(v, c, N, params, shift=None, latency=1024):
+    """What offline.render must return for one recording: the oracle over the zero-padded recording, latency removed."""
+    from oracle import oracle_py as O
+    T = ((len(v) + latency + N - 1) // N) * N
+    x = np.zeros((3, T), np.float32)
+    x[0, :len(v)] = v
+    if c is not None:
+        x[1:3, :min(T, c.shape[-1])] = c[..., :T]
+    o = O.OracleStream(**params)
+    o.prepare_to_play(FS, N)
+    if shift is not None:
+        o.set_pitch_shift(shift)
+    return o.run(x)[:, latency:latency + len(v)]
+
+
+def test_offline_pitch_corrector_ragged_batch_matches_oracle():
+    from vocoderproject_amd import offline
+    N = 1024
+    x = _streams(4, N * 20)
+    voices = [x[0, 0, :20000], x[1, 0, :7777], x[2, 0, :N * 20], x[3, 0, :1500]]
+    shift = [None, 12.0, -7.0, None]
+    outs = offline.pitch_corrector(voices, FS, key=5, shift=shift, blocks_per_call=8)
+    for s, (v, o) in enumerate(zip(voices, outs)):
+        ref = _oracle_offline(v, None, N, dict(vocBool=0, keyPitch=5), shift[s])
+        assert o.shape == (len(v),)
+        _assert_equal(o, ref[0], f"recording {s}")
+    assert np.abs(outs[0]).max() > 0.05
+    # block-by-block calls give the same files as eight blocks per call
+    outs1 = offline.pitch_corrector(voices, FS, key=5, shift=shift, blocks_per_call=1)
+    for a, b in zip(outs, outs1):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_offline_vocode_and_command_line(tmp_path):
+    import subprocess
+    import sys
+    from vocoderproject_amd import offline
+    N = 1024
+    x = _streams(2, N * 12)
+    f_v = [str(tmp_path / "v0.wav"), str(tmp_path / "v1.wav")]
+    f_c = str(tmp_path / "carrier.wav")
+    offline.write_wav(f_v[0], 44100, x[0, 0, :11000])
+    offline.write_wav(f_v[1], 44100, x[1, 0, :6000])
+    offline.write_wav(f_c, 44100, x[0, 1:3, :12000])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "vocoderproject_amd.offline", "vocode", *f_v, "--carrier", f_c,
+                        "--out-dir", str(tmp_path / "out"), "--lpc-voice", "24"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, car = offline.read_wav(f_c)
+    for s in range(2):
+        fs, v = offline.read_wav(f_v[s])
+        fs2, got = offline.read_wav(str(tmp_path / "out" / f"v{s}_vocode.wav"))
+        assert fs == fs2 == 44100 and got.shape == (2, v.shape[1])
+        ref = _oracle_offline(v[0], car, N, dict(pitchBool=0, lpcVoice=24, lpcSynth=5, keyPitch=12))
+        # the file holds the output rounded to 16-bit PCM
+        q = np.rint(np.clip(ref.astype(np.float64), -1, 1) * 32767.0) / 32767.0
+        assert np.abs(got - q.astype(np.float32)).max() <= 1e-7
+        assert np.abs(ref).max() > 0.02

@@ -30,6 +30,7 @@ struct vp_handle {
     int inCounter = 0, outCounter = 0, currCounter = 0, vStart = 0, pStart = 0, nChunk = 0;
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
+    float *stageInB = nullptr, *stageOutB = nullptr; int stageBlocks = 0;   // vp_process_blocks: grow-only, [B][S][3|2][N]
     hipStream_t ownStream = nullptr;
     int vocWaves = 8;
     size_t vocLds = 0, pitchLds = 0;
@@ -151,6 +152,9 @@ static void free_all(vp_handle *h)
     for (void *p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
     h->stageIn = h->stageOut = nullptr;
+    if (h->stageInB) (void)hipFree(h->stageInB);
+    if (h->stageOutB) (void)hipFree(h->stageOutB);
+    h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
     h->prepared = false;
 }
 
@@ -661,6 +665,35 @@ extern "C" int vp_process_blocks_device(vp_handle *h, const float *d_in, float *
         int rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0);
         if (rc) return rc;
     }
+    return VP_OK;
+}
+
+// Host-pointer form of vp_process_blocks_device (offline rendering from a host program without device allocations of
+// its own): one upload, n_blocks blocks, one download, one synchronisation.
+extern "C" int vp_process_blocks(vp_handle *h, const float *in, float *out, int n_blocks)
+{
+    if (!h || !in || !out || n_blocks < 1) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
+    if (n_blocks > h->stageBlocks) {
+        if (h->stageInB) hipFree(h->stageInB);
+        if (h->stageOutB) hipFree(h->stageOutB);
+        h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
+        if (hipMalloc((void **)&h->stageInB, nIn * n_blocks * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&h->stageOutB, nOut * n_blocks * sizeof(float)) != hipSuccess) {
+            if (h->stageInB) hipFree(h->stageInB);
+            h->stageInB = nullptr;
+            h->lastError = "out of device memory for the block staging buffers";
+            return VP_ERR_OOM;
+        }
+        h->stageBlocks = n_blocks;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->stageInB, in, nIn * n_blocks * sizeof(float), hipMemcpyHostToDevice, h->ownStream));
+    int rc = vp_process_blocks_device(h, h->stageInB, h->stageOutB, n_blocks, (void *)h->ownStream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->stageOutB, nOut * n_blocks * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
+    HIPCHK(h, hipStreamSynchronize(h->ownStream));
     return VP_OK;
 }
 

@@ -82,6 +82,8 @@ def load_library():
     if hasattr(L, "vp_set_stream_params"):            # absent only from older builds loaded through VP_AMD_LIB (tools/ab.sh)
         L.vp_set_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vp_get_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "vp_process_blocks"):
+        L.vp_process_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     if hasattr(L, "vp_set_pitch_shift"):
         L.vp_set_pitch_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
         L.vp_get_pitch_shift.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -208,6 +210,10 @@ class BatchVocoderProcessor:
             self._chk(rc)
         return rc
 
+    @property
+    def latency(self):
+        return self.getLatencySamples()
+
     def geometry(self):
         g = (C.c_int * 12)()
         self._chk(self.L.vp_get_geometry(self.h, g))
@@ -246,6 +252,14 @@ class BatchVocoderProcessor:
             import torch
             stream = torch.cuda.current_stream(d_in.device).cuda_stream
         self._chk(self.L.vp_process_blocks_device(self.h, d_in.data_ptr(), d_out.data_ptr(), int(B), C.c_void_p(stream)))
+
+    def process_blocks(self, x):
+        """vp_process_blocks: float32 numpy [B][S][3][N] -> new float32 [B][S][2][N], same results as B calls of
+        process() (pitch corrector alone: one launch; used by the offline front end)."""
+        assert x.dtype == np.float32 and x.flags.c_contiguous and x.ndim == 4 and x.shape[1:] == (self.n_streams, 3, self.N), x.shape
+        out = np.empty((x.shape[0], self.n_streams, 2, self.N), np.float32)
+        self._chk(self.L.vp_process_blocks(self.h, x.ctypes.data, out.ctypes.data, int(x.shape[0])))
+        return out
 
     def run(self, x):
         """x: float32 numpy [S][3][T], T a multiple of N -> float32 [S][2][T] (block by block)."""
