@@ -91,14 +91,14 @@ def cpu_baseline(mode, N, seconds_target=12.0):
                       f"{dt:.1f} s wall"}
 
 
-def measured_traffic(mode, S, N, iir):
+def measured_traffic(mode, S, N, iir, mono=False):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this very command); None when the
     configuration being benched is not the one that was profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
             t = json.load(f)
-        key = f"{mode}/S{S}/N{N}/{iir}"
+        key = f"{mode}{'-mono' if mono else ''}/S{S}/N{N}/{iir}"
         return t["per_launch_bytes"].get(key)
     except (OSError, ValueError, KeyError):
         return None
@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--shift", type=float, default=None,
                     help="extension (no reference counterpart): fixed pitch-shift interval in semitones, +x on even and -x "
                          "on odd streams (vp_set_pitch_shift), instead of the correction to the key's nearest note")
+    ap.add_argument("--three-channel", action="store_true",
+                    help="pitch mode: hand over [S][3][N] buffers (voice + zero side chain) instead of the mono voice buffers "
+                         "configs[1] describes (vp_process_block_mono_device; same output, a third of the input bytes)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -190,12 +193,23 @@ def main():
     y = torch.empty((BPS, S, 2, N), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
+    # configs[1] is "256 MONO streams": the pitch-only workload hands over the voice alone (the plugin's null side-chain
+    # pointers, MyBuffer.cpp:93-102); vocoder workloads carry the stereo side chain
+    mono = mode == "pitch" and not args.three_channel
+    xm = x[:, :, 0, :].contiguous() if mono else None                          # [U][S][N]
+
     def step(i):
         if BPS == 1:
-            p.process_device(x[i % U], y[0], stream.cuda_stream)
+            if mono:
+                p.process_mono_device(xm[i % U], y[0], stream.cuda_stream)
+            else:
+                p.process_device(x[i % U], y[0], stream.cuda_stream)
         else:
             b0 = (i * BPS) % U
-            p.process_blocks_device(x[b0:b0 + BPS], y, stream.cuda_stream)
+            if mono:
+                p.process_blocks_mono_device(xm[b0:b0 + BPS], y, stream.cuda_stream)
+            else:
+                p.process_blocks_device(x[b0:b0 + BPS], y, stream.cuda_stream)
 
     def timed(mode_iir, steps, warmup):
         p.set_iir_mode(mode_iir)
@@ -231,15 +245,20 @@ def main():
     if not args.single_mode and BPS == 1 and mode == "pitch" and U % MB == 0:
         ymb = torch.empty((MB, S, 2, N), dtype=torch.float32, device=dev)
         p.set_iir_mode(args.iir)
+        def step_mb(b0):
+            if mono:
+                p.process_blocks_mono_device(xm[b0:b0 + MB], ymb, stream.cuda_stream)
+            else:
+                p.process_blocks_device(x[b0:b0 + MB], ymb, stream.cuda_stream)
+
         for i in range(2):
-            p.process_blocks_device(x[0:MB], ymb, stream.cuda_stream)
+            step_mb(0)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(k3):
-            b0 = (i * MB) % U
-            p.process_blocks_device(x[b0:b0 + MB], ymb, stream.cuda_stream)
+            step_mb((i * MB) % U)
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -283,7 +302,7 @@ def main():
             "config": {"workload": f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
                                    f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
-                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "frames_per_step": frames_per_step_gpu * n_gpus,
+                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "input": "mono voice [S][N]" if mono else "[S][3][N]", "frames_per_step": frames_per_step_gpu * n_gpus,
                        "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -300,7 +319,7 @@ def main():
         }
         if not args.single_mode:
             out["stft_kernel"] = stft_figure(dev, S)
-        out["roofline"]["traffic"] = measured_traffic(mode, S, N, args.iir) if BPS == 1 else None
+        out["roofline"]["traffic"] = measured_traffic(mode, S, N, args.iir, mono) if BPS == 1 else None
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
         print(json.dumps(out))

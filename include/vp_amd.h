@@ -120,6 +120,14 @@ int vp_process_block_inplace(vp_handle *h, float *io);
  * the layouts above; kernels are enqueued on `hip_stream` (a hipStream_t, may be NULL = default
  * stream) and the call returns without synchronising. */
 int vp_process_block_device(vp_handle *h, const float *d_in, float *d_out, void *hip_stream);
+/* processBlock() on buffers without the side-chain bus (mono voice in, stereo out): voice float [n_streams][N].
+ * MyBuffer::fillInputBuffers takes null side-chain pointers and fills the synth ring with zeros (MyBuffer.cpp:93-102);
+ * results are identical to vp_process_block with zeroed ch1/ch2, at a third of the input traffic.  May be mixed freely
+ * with the three-channel calls. */
+int vp_process_block_mono(vp_handle *h, const float *voice, float *out);
+int vp_process_block_mono_device(vp_handle *h, const float *d_voice, float *d_out, void *hip_stream);
+/* n_blocks of them at once: d_voice float [n_blocks][n_streams][N] (the mono form of vp_process_blocks_device below) */
+int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_out, int n_blocks, void *hip_stream);
 /* n_blocks consecutive processBlock() calls at once (offline rendering, servers with audio queued up):
  * d_in float [n_blocks][n_streams][3][N], d_out float [n_blocks][n_streams][2][N], i.e. block b's slabs are what
  * vp_process_block_device would take.  Results are identical to n_blocks single calls.  With the pitch corrector alone

@@ -103,6 +103,16 @@ public:
     {
         check(vp_process_block_device(h_, dIn, dOut, hipStream), "processBlockDevice");
     }
+    // buffers without the side-chain bus: voice [streams][N] (null side-chain pointers -> zeros, MyBuffer.cpp:93-102)
+    void processBlockMono(const float *voice, float *out) { check(vp_process_block_mono(h_, voice, out), "processBlockMono"); }
+    void processBlockMonoDevice(const float *dVoice, float *dOut, void *hipStream = nullptr)
+    {
+        check(vp_process_block_mono_device(h_, dVoice, dOut, hipStream), "processBlockMonoDevice");
+    }
+    void processBlocksMonoDevice(const float *dVoice, float *dOut, int nBlocks, void *hipStream = nullptr)
+    {
+        check(vp_process_blocks_mono_device(h_, dVoice, dOut, nBlocks, hipStream), "processBlocksMonoDevice");
+    }
     // nBlocks consecutive processBlock() calls at once: dIn [nBlocks][streams][3][N], dOut [nBlocks][streams][2][N]
     void processBlocksDevice(const float *dIn, float *dOut, int nBlocks, void *hipStream = nullptr)
     {

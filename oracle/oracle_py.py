@@ -66,6 +66,7 @@ def lib():
         L.vpo_prepare_to_play.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.vpo_prepare_explicit.argtypes = [C.c_void_p, C.c_double] + [C.c_int] * 5
         L.vpo_process_block.argtypes = [C.c_void_p, fp, fp, fp]
+        L.vpo_process_block_mono.argtypes = [C.c_void_p, fp, fp, fp]
         L.vpo_get_latency.argtypes = [C.c_void_p]
         L.vpo_get_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.vpo_trace_count.argtypes = [C.c_void_p]
@@ -161,6 +162,16 @@ class OracleStream:
                                       io[2].ctypes.data_as(fp))
         if rc:
             raise RuntimeError(f"process_block rc={rc}")
+
+    def process_block_mono(self, voice):
+        """voice: float32 [N]; side chain absent (null pointers -> zeros).  Returns float32 [2][N]."""
+        assert voice.dtype == np.float32 and voice.shape == (self._N,) and voice.flags.c_contiguous
+        out = np.empty((2, self._N), np.float32)
+        fp = C.POINTER(C.c_float)
+        rc = self.L.vpo_process_block_mono(self.h, voice.ctypes.data_as(fp), out[0].ctypes.data_as(fp), out[1].ctypes.data_as(fp))
+        if rc:
+            raise RuntimeError(f"process_block_mono rc={rc}")
+        return out
 
     def run(self, x, trace=False):
         """x: float32 [3][T] with T a multiple of N. Returns float32 [2][T] (and per-frame traces)."""

@@ -1038,7 +1038,21 @@ int vpo_prepare_to_play(vpo *o, double sampleRate, int samplesPerBlock)     /* :
     return vpo_prepare_explicit(o, sampleRate, samplesPerBlock, frameLenPitch, hopPitch, wlenVoc, hopVoc);
 }
 
+static int process_block_io(vpo *o, const float *in0, const float *in1, const float *in2, float *ch0, float *ch1, float *ch2);
+
 int vpo_process_block(vpo *o, float *ch0, float *ch1, float *ch2)          /* :203-234 */
+{
+    return process_block_io(o, ch0, ch1, ch2, ch0, ch1, ch2);
+}
+
+/* processBlock on a buffer whose side-chain bus is absent: MyBuffer::fillInputBuffers gets null side-chain pointers
+ * and fills the synth ring with zeros (MyBuffer.cpp:93-102). */
+int vpo_process_block_mono(vpo *o, const float *voice, float *outL, float *outR)
+{
+    return process_block_io(o, voice, NULL, NULL, outL, outR, NULL);
+}
+
+static int process_block_io(vpo *o, const float *in0, const float *in1, const float *in2, float *ch0, float *ch1, float *ch2)
 {
     if (!o->prepared) return -1;
 #ifdef VPO_HAVE_MXCSR
@@ -1046,7 +1060,7 @@ int vpo_process_block(vpo *o, float *ch0, float *ch1, float *ch2)          /* :2
     if (o->ftz) _mm_setcsr(saved | 0x8040);                                  /* ScopedNoDenormals: FTZ | DAZ */
 #endif
     o->traceN = 0;
-    fill_input_buffers(o, ch0, ch1, ch2);
+    fill_input_buffers(o, in0, in1, in2);
     if (o->vocBool) vocoder_process(o);
     if (o->pitchBool) pitch_process(o); else pitch_silence(o);
     if (o->gainVoice > -59.0) add_dry_voice(o, vpo_db_to_gain_f(o->gainVoice));

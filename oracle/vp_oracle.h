@@ -70,6 +70,8 @@ int vpo_prepare_explicit(vpo *o, double sampleRate, int samplesPerBlock,
 /* In-place 3 x N float buffer: ch0 voice -> out L, ch1 synth L -> out R, ch2 synth R -> 0.
  * ch1/ch2 may be NULL (sidechain absent, MyBuffer.cpp:93-102); then out R is not written. :203-234 */
 int vpo_process_block(vpo *o, float *ch0, float *ch1, float *ch2);
+/* the same with the side-chain bus absent (null pointers -> zeros, MyBuffer.cpp:93-102); out of place */
+int vpo_process_block_mono(vpo *o, const float *voice, float *outL, float *outR);
 int vpo_get_latency(const vpo *o);
 int vpo_get_geometry(const vpo *o, int out[12]); /* N,F,H,C,W,h,toKeep,latency,inSize,outSize,tauMax,chunksPerFrame */
 /* Frames started during the most recent process_block call. */

@@ -937,3 +937,72 @@ def test_offline_vocode_and_command_line(tmp_path):
         q = np.rint(np.clip(ref.astype(np.float64), -1, 1) * 32767.0) / 32767.0
         assert np.abs(got - q.astype(np.float32)).max() <= 1e-7
         assert np.abs(ref).max() > 0.02
+
+
+# ---- buffers without the side-chain bus (MyBuffer.cpp:93-102: null pointers -> zeros) -----------------------------------
+
+@pytest.mark.parametrize("params", [dict(), dict(vocBool=0), dict(gainSynth=-10.0, gainVoice=-8.0)])
+def test_mono_entry_matches_null_sidechain(params):
+    """vp_process_block_mono: voice only, the synth ring takes zeros like fillInputBuffers with null side-chain pointers;
+    mixed with three-channel calls so that the ring goes through 'holds carrier', 'partly zeroed' and 'all zero'."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 5, 1024, 22
+    x = _streams(S, N * B)
+    kinds = "33333mmmmmmm333mmmmm3m"                                  # 3 = three channels, m = mono
+    assert len(kinds) == B
+    p = BatchVocoderProcessor(**params)
+    p.prepareToPlay(FS, N, S)
+    os_ = []
+    for s_ in range(S):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(FS, N)
+        os_.append(o)
+    nonzero = 0
+    for b in range(B):
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        if kinds[b] == "3":
+            got = p.process(blk)
+        else:
+            got = p.process_mono(np.ascontiguousarray(blk[:, 0]))
+        for s_ in range(S):
+            if kinds[b] == "3":
+                io = blk[s_].copy()
+                os_[s_].process_block(io)
+                ref = io[:2]
+            else:
+                ref = os_[s_].process_block_mono(np.ascontiguousarray(blk[s_, 0]))
+            _assert_equal(got[s_], ref, f"block {b} ({kinds[b]}) stream {s_}")
+        nonzero += int(np.abs(got).max() > 0.01)
+    assert nonzero > B // 2
+
+
+def test_mono_entry_device_and_multi_block_forms():
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 6, 1024, 16
+    x = _streams(S, N * B)
+    v = np.ascontiguousarray(x[:, 0].reshape(S, B, N).transpose(1, 0, 2))            # [B][S][N]
+    x0 = x.copy()
+    x0[:, 1:] = 0
+    ref, _ = _gpu_run(x0, N, dict(vocBool=0))                                       # three channels, zeroed side chain
+    dev = torch.device("cuda", 0)
+    dv = torch.from_numpy(v).to(dev)
+    # block by block on the device
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    dout = torch.empty((S, 2, N), dtype=torch.float32, device=dev)
+    for b in range(B):
+        p.process_mono_device(dv[b], dout)
+        torch.cuda.synchronize()
+        _assert_equal(dout.cpu().numpy(), ref[:, :, b * N:(b + 1) * N], f"mono device block {b}")
+    # eight blocks per call (one launch)
+    p2 = BatchVocoderProcessor(vocBool=0)
+    p2.prepareToPlay(FS, N, S)
+    dout8 = torch.empty((8, S, 2, N), dtype=torch.float32, device=dev)
+    for b0 in range(0, B, 8):
+        p2.process_blocks_mono_device(dv[b0:b0 + 8], dout8)
+        torch.cuda.synchronize()
+        y = dout8.cpu().numpy()
+        for j in range(8):
+            _assert_equal(y[j], ref[:, :, (b0 + j) * N:(b0 + j + 1) * N], f"mono multi block {b0 + j}")

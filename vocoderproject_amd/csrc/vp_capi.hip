@@ -30,6 +30,7 @@ struct vp_handle {
     int inCounter = 0, outCounter = 0, currCounter = 0, vStart = 0, pStart = 0, nChunk = 0;
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
+    int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
     float *stageInB = nullptr, *stageOutB = nullptr; int stageBlocks = 0;   // vp_process_blocks: grow-only, [B][S][3|2][N]
     hipStream_t ownStream = nullptr;
     int vocWaves = 8;
@@ -499,6 +500,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     h->vStart = 0; h->pStart = 0; h->nChunk = 0;                             // VocoderProcess.cpp:39, PitchProcess.cpp:85,90
     h->sparams.assign((size_t)S, h->params);                                 // prepare starts every stream from the handle's set
     h->spHost.assign((size_t)S, VpStreamParams{});
+    h->synthNonZero = 0;                                                     // the rings start zeroed
     h->shiftOn.assign((size_t)S, 0); h->shiftSemi.assign((size_t)S, 0.0); h->shiftBeta.assign((size_t)S, 1.0);
     h->perStream = false; h->spDirty = true;                                 // the fresh (zeroed) state needs them
     h->prepared = true;
@@ -552,7 +554,7 @@ static void fill_stream_params(VpStreamParams &o, const vp_params &P)
     o.gainSynth = (double)db_to_gain_f(P.gainSynth);
 }
 
-static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace, int nBlocks = 1)
+static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace, int nBlocks = 1, bool mono = false)
 {
     const VpGeom &g = h->g;
     const vp_params P = h->params;                                           // snapshot at call entry
@@ -564,6 +566,15 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
     c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
     c.iirFast = h->iirMode;
     c.nBlocks = 1;
+    // side-chain bus present or absent; the synth ring is written N samples per call, so after inSize samples of zeros
+    // (or straight after prepare) it holds nothing else and the mono path need not touch it
+    if (mono) {
+        c.inMono = h->synthNonZero > 0 ? 1 : 2;
+        h->synthNonZero = std::max(0, h->synthNonZero - g.N * nBlocks);
+    } else {
+        c.inMono = 0;
+        h->synthNonZero = g.inSize;
+    }
     c.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
     c.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
     if (h->spDirty) {
@@ -651,7 +662,7 @@ extern "C" int vp_process_block_device(vp_handle *h, const float *d_in, float *d
     return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0);
 }
 
-extern "C" int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream)
+static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream, bool mono)
 {
     if (!h || !d_in || !d_out || n_blocks < 1) return VP_ERR_INVALID_ARG;
     if (!h->prepared) return VP_ERR_NOT_PREPARED;
@@ -659,12 +670,48 @@ extern "C" int vp_process_blocks_device(vp_handle *h, const float *d_in, float *
     const vp_params &P = h->params;
     const bool fast = h->iirMode == VP_IIR_FAST, fft = h->yinMode == VP_YIN_FFT && h->g.fftLog > 0;
     if (P.pitchBool && !P.vocBool && n_blocks > 1 && !fft && !pitch_lite(h, fast, fft))   // one launch: state stays on chip between the blocks
-        return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks);
-    const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
+        return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
+    const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
     for (int b = 0; b < n_blocks; b++) {                       // other plans: block by block
-        int rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0);
+        int rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0, 1, mono);
         if (rc) return rc;
     }
+    return VP_OK;
+}
+
+extern "C" int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream)
+{
+    return process_blocks_device(h, d_in, d_out, n_blocks, hip_stream, false);
+}
+
+// voice [n_blocks][S][N] -> [n_blocks][S][2][N]: the mono form of the above
+extern "C" int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_out, int n_blocks, void *hip_stream)
+{
+    return process_blocks_device(h, d_voice, d_out, n_blocks, hip_stream, true);
+}
+
+// processBlock() on buffers WITHOUT the side-chain bus: voice [S][N] only.  The reference's fillInputBuffers takes null
+// side-chain pointers and fills the synth ring with zeros (MyBuffer.cpp:93-102); same here, without reading or (once
+// the ring is known to be all zero) writing anything for it.
+extern "C" int vp_process_block_mono_device(vp_handle *h, const float *d_voice, float *d_out, void *hip_stream)
+{
+    if (!h || !d_voice || !d_out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    return process_device(h, d_voice, d_out, (hipStream_t)hip_stream, 0, 1, true);
+}
+
+extern "C" int vp_process_block_mono(vp_handle *h, const float *voice, float *out)
+{
+    if (!h || !voice || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    const size_t nIn = (size_t)h->g.S * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
+    HIPCHK(h, hipMemcpyAsync(h->stageIn, voice, nIn * sizeof(float), hipMemcpyHostToDevice, h->ownStream));
+    int rc = process_device(h, h->stageIn, h->stageOut, h->ownStream, 0, 1, true);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->stageOut, nOut * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
+    HIPCHK(h, hipStreamSynchronize(h->ownStream));
     return VP_OK;
 }
 
@@ -677,12 +724,12 @@ extern "C" int vp_process_blocks(vp_handle *h, const float *in, float *out, int 
     if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
     if (n_blocks > h->stageBlocks) {
-        if (h->stageInB) hipFree(h->stageInB);
-        if (h->stageOutB) hipFree(h->stageOutB);
+        if (h->stageInB) (void)hipFree(h->stageInB);
+        if (h->stageOutB) (void)hipFree(h->stageOutB);
         h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
         if (hipMalloc((void **)&h->stageInB, nIn * n_blocks * sizeof(float)) != hipSuccess ||
             hipMalloc((void **)&h->stageOutB, nOut * n_blocks * sizeof(float)) != hipSuccess) {
-            if (h->stageInB) hipFree(h->stageInB);
+            if (h->stageInB) (void)hipFree(h->stageInB);
             h->stageInB = nullptr;
             h->lastError = "out of device memory for the block staging buffers";
             return VP_ERR_OOM;

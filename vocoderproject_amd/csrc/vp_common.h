@@ -46,6 +46,9 @@ struct VpCall {
     int yinCert;                 // 1: cross-correlation form of the difference function (fused multiply-adds)
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
     int ldsBytes;                // dynamic LDS of this launch (used by the -DVP_POISON_LDS diagnostic build only)
+    int inMono;                  // 0: input [S][3][N].  1: input [S][N], side-chain bus absent -> the synth ring takes zeros
+                                 // (MyBuffer.cpp:93-102).  2: same, and the host knows the synth ring holds nothing but zeros
+                                 // already (nothing to write, nothing to sum for its gate)
     int nBlocks;                 // pitch kernel with both fusions: consecutive blocks handled by this launch (>= 1);
                                  // the counters above describe the first, the kernel advances them itself
 };

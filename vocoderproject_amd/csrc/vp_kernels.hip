@@ -140,20 +140,38 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
     float *vr = d.voiceRing + (size_t)s * g.inSize;
     float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     float *sr1 = sr0 + g.inSize;
-    const float *xin = in + (size_t)s * 3 * g.N;
-    for (int i = tid; i < g.N; i += nt) {
-        int p = (c.inCounter + boff + i) % g.inSize;
-        vr[p] = xin[i];
-        sr0[p] = xin[g.N + i];
-        sr1[p] = xin[2 * g.N + i];
+    const int mono = c.inMono;
+    const float *xin = in + (size_t)s * (mono ? 1 : 3) * g.N;
+    if (!mono) {
+        for (int i = tid; i < g.N; i += nt) {
+            int p = (c.inCounter + boff + i) % g.inSize;
+            vr[p] = xin[i];
+            sr0[p] = xin[g.N + i];
+            sr1[p] = xin[2 * g.N + i];
+        }
+    } else {                                           // null side-chain pointers: zeros (MyBuffer.cpp:93-102)
+        for (int i = tid; i < g.N; i += nt) {
+            int p = (c.inCounter + boff + i) % g.inSize;
+            vr[p] = xin[i];
+            if (mono == 1) { sr0[p] = 0.0f; sr1[p] = 0.0f; }
+        }
     }
     __syncthreads();   // own-workgroup global writes are visible to the workgroup after the barrier
 
+    // the side chain's gate is only consulted by the vocoder (VocoderProcess.cpp:199-204); an all-zero ring sums to 0
+    const bool needS = c.vocOn && mono != 2;
     double sv = 0.0, ss = 0.0;
-    for (int i = tid; i < g.inSize; i += nt) {
-        double a = (double)vr[i], b = (double)sr0[i];
-        sv += a * a;
-        ss += b * b;
+    if (needS) {
+        for (int i = tid; i < g.inSize; i += nt) {
+            double a = (double)vr[i], b = (double)sr0[i];
+            sv += a * a;
+            ss += b * b;
+        }
+    } else {
+        for (int i = tid; i < g.inSize; i += nt) {
+            double a = (double)vr[i];
+            sv += a * a;
+        }
     }
     sv = wave_sum(sv);
     ss = wave_sum(ss);
@@ -2208,7 +2226,7 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         boff += g.N;
         pS -= g.N;
         nSteps = (pS < g.N) ? (g.N - pS + g.C - 1) / g.C : 0;
-        in += (size_t)g.S * 3 * g.N;
+        in += (size_t)g.S * (c.inMono ? 1 : 3) * g.N;
         out += (size_t)g.S * (c.inplace ? 3 : 2) * g.N;
         __syncthreads();                              // the previous block's emit has read what the ingest overwrites
         ingest_gate_block(g, c, d, in, boff);

@@ -82,6 +82,10 @@ def load_library():
     if hasattr(L, "vp_set_stream_params"):            # absent only from older builds loaded through VP_AMD_LIB (tools/ab.sh)
         L.vp_set_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vp_get_stream_params.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if hasattr(L, "vp_process_block_mono"):
+        L.vp_process_block_mono.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vp_process_block_mono_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vp_process_blocks_mono_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     if hasattr(L, "vp_process_blocks"):
         L.vp_process_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     if hasattr(L, "vp_set_pitch_shift"):
@@ -232,6 +236,32 @@ class BatchVocoderProcessor:
         out = np.empty((self.n_streams, 2, self.N), np.float32)
         self._chk(self.L.vp_process_block(self.h, x.ctypes.data, out.ctypes.data))
         return out
+
+    def process_mono(self, voice):
+        """Buffers without the side-chain bus: float32 numpy [S][N] -> new float32 [S][2][N] (== process() with zeroed ch1/ch2)."""
+        assert voice.dtype == np.float32 and voice.flags.c_contiguous and voice.shape == (self.n_streams, self.N)
+        out = np.empty((self.n_streams, 2, self.N), np.float32)
+        self._chk(self.L.vp_process_block_mono(self.h, voice.ctypes.data, out.ctypes.data))
+        return out
+
+    def process_mono_device(self, d_voice, d_out, stream=None):
+        """Device-resident mono entry: torch float32 tensors [S][N] -> [S][2][N]."""
+        assert d_voice.is_cuda and d_out.is_cuda and d_voice.is_contiguous() and d_out.is_contiguous()
+        assert tuple(d_voice.shape) == (self.n_streams, self.N) and tuple(d_out.shape) == (self.n_streams, 2, self.N)
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(d_voice.device).cuda_stream
+        self._chk(self.L.vp_process_block_mono_device(self.h, d_voice.data_ptr(), d_out.data_ptr(), C.c_void_p(stream)))
+
+    def process_blocks_mono_device(self, d_voice, d_out, stream=None):
+        """B consecutive mono blocks at once: torch float32 [B][S][N] -> [B][S][2][N]."""
+        assert d_voice.is_cuda and d_out.is_cuda and d_voice.is_contiguous() and d_out.is_contiguous()
+        B = d_voice.shape[0]
+        assert tuple(d_voice.shape) == (B, self.n_streams, self.N) and tuple(d_out.shape) == (B, self.n_streams, 2, self.N)
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(d_voice.device).cuda_stream
+        self._chk(self.L.vp_process_blocks_mono_device(self.h, d_voice.data_ptr(), d_out.data_ptr(), int(B), C.c_void_p(stream)))
 
     def process_device(self, d_in, d_out, stream=None):
         """Device-resident, asynchronous: torch CUDA(HIP) float32 tensors [S][3][N] -> [S][2][N]."""
