@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--three-channel", action="store_true",
                     help="pitch mode: hand over [S][3][N] buffers (voice + zero side chain) instead of the mono voice buffers "
                          "configs[1] describes (vp_process_block_mono_device; same output, a third of the input bytes)")
+    ap.add_argument("--cfg5", action="store_true",
+                    help="BASELINE configs[4] geometry instead of the default one: 48 kHz, 2048-point frames hop 512 (pitch "
+                         "2048/1536, vocoder 2048/512), LPC orders 48/48/30, host block 2048 (a documentation figure: use with --mode both --no-cpu)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -173,8 +176,15 @@ def main():
     n_gpus = world
 
     S, N, mode = args.streams, args.block, args.mode
-    p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"))
-    p.prepareToPlay(FS, N, S)
+    global FS, HOP
+    if args.cfg5:
+        FS, HOP, N = 48000.0, 512, 2048
+        p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"),
+                                  lpcVoice=48, lpcPitch=48, lpcSynth=30)
+        p.prepareExplicit(FS, N, S, 2048, 1536, 2048, 512)
+    else:
+        p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"))
+        p.prepareToPlay(FS, N, S)
     p.set_yin_mode(args.yin)
 
     def set_shift(semi):
@@ -292,14 +302,14 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else dom
         ms, n = prof[dom]
         avg_s = (ms / max(n, 1)) * 1e-3
-        alg_bytes = ALG_BYTES_PER_FRAME[mode] * frames_per_step_gpu
+        alg_bytes = ALG_BYTES_PER_FRAME[mode] * (HOP // 256) * frames_per_step_gpu      # f32 I/O per hop-frame (hop 512: twice the samples)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
             "metric": "STFT-geometry frames/sec (1024-pt frames, hop 256) through the pitch-corrector/vocoder path",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
+            "config": {"workload": (f"configs[4] geometry: {S} streams per GPU @48 kHz, 2048-pt frames hop 512, LPC orders 48/48/30, mode {mode}, host block N={N}" if args.cfg5 else "") or f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
                                    f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
                        "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "input": "mono voice [S][N]" if mono else "[S][3][N]", "frames_per_step": frames_per_step_gpu * n_gpus,

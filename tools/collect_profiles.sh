@@ -11,8 +11,7 @@ python bench.py --mode both --no-cpu > $out/${tag}_both_bench.json 2>> $out/benc
 python bench.py --mode voc --no-cpu > $out/${tag}_voc_bench.json 2>> $out/bench.err
 python bench.py --streams 1024 --no-cpu --single-mode > $out/${tag}_pitch_s1024_bench.json 2>> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py --no-cpu --single-mode > $out/${tag}_pitch_cfg2_bench_under_rocprof.json 2> $out/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 40 --warmup 4 --no-cpu --single-mode > /dev/null 2> $out/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 40 --warmup 4 --no-cpu --single-mode > /dev/null 2> $out/pmc_write.err
+bash tools/pmc_traffic.sh $tag > $out/pmc_traffic.txt 2>&1     # FETCH_SIZE / WRITE_SIZE, separate passes, mono and three-channel input
 python tools/phase_stamps.py --mode both --iir fast --yin xcorr > $out/${tag}_phase_stamps_both_fast.txt 2>/dev/null
 python tools/phase_stamps.py --mode both --iir exact > $out/${tag}_phase_stamps_both_exact.txt 2>/dev/null
 find $out -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
