@@ -611,7 +611,9 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             int nw = std::min(h->vocWaves, c.nWin);
             if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
             cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
-            hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(64 * nw), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
+            cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
+            const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
+            hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
         }
         if (runPitch) {
             VpCall cp = c;

@@ -46,6 +46,9 @@ struct VpCall {
     int yinCert;                 // 1: cross-correlation form of the difference function (fused multiply-adds)
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
     int ldsBytes;                // dynamic LDS of this launch (used by the -DVP_POISON_LDS diagnostic build only)
+    int vocWin;                  // vocoder kernel: windows per round (= window slots in LDS).  The launch carries a whole
+                                 // number of wavefronts per slot: wave r * vocWin + j works for window j in role r (role 0 owns
+                                 // it; the others take their share of the autocorrelation passes and residual-FIR units)
     int inMono;                  // 0: input [S][3][N].  1: input [S][N], side-chain bus absent -> the synth ring takes zeros
                                  // (MyBuffer.cpp:93-102).  2: same, and the host knows the synth ring holds nothing but zeros
                                  // already (nothing to write, nothing to sum for its gate)

@@ -429,9 +429,10 @@ __device__ __forceinline__ void energy_pair_wave(EP e0, EP e1, int n, double &E0
 // VocoderProcess::filterFIR (VocoderProcess.cpp:235-251) for one window by one wavefront:
 // e[i] = a[0]*xw[i] + sum_{k=1..min(order,i)} xw[i-k]*a[k].
 template <class XP, class AP, class EP>
-__device__ __forceinline__ void fir_window8(XP xw, AP a, int order, int W, EP e, int lane)
+__device__ __forceinline__ void fir_window8(XP xw, AP a, int order, int W, EP e, int lane, int unit0 = 0, int unitStep = 1)
 {
-    for (int i0 = 0; i0 < W; i0 += 8 * WAVE) {
+    // units of 8 x 64 outputs; a caller that shares the window with other wavefronts takes units unit0, unit0 + unitStep, ...
+    for (int i0 = unit0 * 8 * WAVE; i0 < W; i0 += unitStep * 8 * WAVE) {
         double acc[8];
         int idx[8];
 #pragma unroll
@@ -725,7 +726,13 @@ __device__ __forceinline__ void iir_block_wave_regs(const lds_f64 *x, lds_f64 *y
 __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, const VpDev &d, double *smem)
 {
     const int s = blockIdx.x, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, nWaves = blockDim.x >> 6;
+    const int waveHw = tid >> 6, lane = tid & 63, nWaves = c.vocWin;      // nWaves: windows per round
+    // The launch carries nRoles wavefronts per window slot: wavefront waveHw works for window waveHw % vocWin in role
+    // waveHw / vocWin.  Role 0 owns the window (everything ordered or serial); the others share its storage and take
+    // their part of the lane-parallel phases (autocorrelation passes, residual-FIR units).
+    const int role = waveHw / nWaves, wave = waveHw - role * nWaves;
+    const int nRoles = (int)(blockDim.x >> 6) / nWaves;                   // the host launches a whole number of them
+    const bool helper = role != 0;
     if (!(d.gate[s * 2 + 0] && d.gate[s * 2 + 1])) return;     // :199-204, whole workgroup
 
     const VpStreamParams sp = d.pitch[s].sp;              // this stream's treeState values (one uniform read)
@@ -751,7 +758,8 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 
     for (int w0 = 0; w0 < c.nWin; w0 += nWaves) {
         const int w = w0 + wave;
-        const bool active = w < c.nWin;
+        const bool activeW = w < c.nWin && role < nRoles;      // the window of this wavefront (own or helped) is in the round
+        const bool active = activeW && !helper;                // ... and this wavefront owns it
         const int nAct = min(nWaves, c.nWin - w0);
         const int start = c.vStart + w * g.h;
 
@@ -769,11 +777,12 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 
         // biaisedAutoCorr (LPC.cpp:44-97) for voice lags 0..oV and synth lags 0..oS: one lane per
         // lag, each lag its own left-to-right sum over n.
-        if (active) {
+        if (activeW) {
             const int nLags = oV + 1 + oS + 1;
             // whole wavefronts (spare lanes redo the last lag, no store): partial-EXEC loops are slow
-            // here; eight elements are read ahead per trip, the sum stays left to right
-            for (int q0 = lane; (q0 & ~(WAVE - 1)) < nLags; q0 += WAVE) {
+            // here; eight elements are read ahead per trip, the sum stays left to right.
+            // More than 64 lags (orders 48/30) take several passes: pass k goes to role k % nRoles.
+            for (int q0 = role * WAVE + lane; (q0 & ~(WAVE - 1)) < nLags; q0 += nRoles * WAVE) {
                 const int q = min(q0, nLags - 1);
                 const bool isV = q <= oV;
                 const int m = isV ? q : q - (oV + 1);
@@ -812,12 +821,15 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         // Eight output samples per lane side by side (independent accumulators, taps in the inner
         // position in the reference's order k = 1..order); a tap that reaches left of the window
         // contributes an exact 0.
-        if (active) {
-            fir_window8(B, aV, oV, W, D, lane);
-        }
-        __syncthreads();     // A (raw samples) is dead from here: it becomes eSynth
-        if (active) {
-            fir_window8(Cc, aS, oS, W, A, lane);
+        // The two residuals touch disjoint arrays (voice: B -> D, carrier: Cc -> A; A's raw samples are dead since the
+        // barrier behind the autocorrelation) and every output is its own sum, so the roles share them freely.
+        // Work units of 512 outputs, the voice's first, then the carrier's: unit j goes to role j % nRoles.
+        if (activeW) {
+            const int nU = (W + 8 * WAVE - 1) / (8 * WAVE);
+            const int v0 = role;                                            // first voice unit of this role
+            const int s0 = ((role - nU) % nRoles + nRoles) % nRoles;        // first carrier unit: nU + s0 = role (mod nRoles)
+            fir_window8(B, aV, oV, W, D, lane, v0, nRoles);
+            fir_window8(Cc, aS, oS, W, A, lane, s0, nRoles);
         }
         __syncthreads();
         STAMP(d, 19);
@@ -830,7 +842,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         STAMP(d, 20);
 
         // filterIIR part 1 (VocoderProcess.cpp:264-275): 10-deep energy histories, window by window.
-        if (wave == 0) {                                 // all lanes redundantly (full EXEC)
+        if (waveHw == 0) {                               // all lanes redundantly (full EXEC)
             for (int j = 0; j < nAct; j++) {
                 for (int i = 9; i > 0; i--) { hist[i] = hist[i - 1]; hist[10 + i] = hist[10 + i - 1]; }
                 hist[0] = roundE[j];
@@ -857,7 +869,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         // tools/ubench_iir.hip modes 1 vs 3).  Spare lanes redo the last window (identical stores).
         if (c.iirFast) {
             if (active) iir_fast_wave(A, B, W, aV, oV, (const lds_f64 *)nullptr, gArr[wave]);   // wave per window, lanes over taps
-        } else if (wave == 0) {
+        } else if (waveHw == 0) {
             const int wj = min(lane, nAct - 1);
             lds_f64 *wb = gArr + 8 + (size_t)wj * voc_wave_doubles(W);        // window `wj` of this round
             const lds_f64 *Aj = wb, *aVj = wb + 4 * (size_t)W + (VP_ORDER_MAX + 1);
