@@ -426,6 +426,41 @@ __device__ __forceinline__ void energy_pair_wave(EP e0, EP e1, int n, double &E0
     E0 = r0; E1 = r1;
 }
 
+// One array's left-to-right sum of e[i]^2, same arithmetic as a half of energy_pair_wave (for callers that give the two
+// sums to two wavefronts).
+template <class EP>
+__device__ __forceinline__ double energy_wave(EP e0, int n)
+{
+    double r0 = 0.0;
+    if ((n & 15) == 0) {
+        const int l16 = threadIdx.x & 15;
+        const double one = 1.0;
+        double v0 = e0[l16];
+        for (int i = 0; i < n; i += 16) {
+            double s0 = v0 * v0;
+            if (i + 16 < n) v0 = e0[i + 16 + l16];
+            asm volatile("s_nop 1" : "+v"(s0));                                // VALU write -> DPP read
+#define VP_EN(U) VP_FMAC_BCAST(r0, s0, one, U);
+            VP_EN(0) VP_EN(1) VP_EN(2) VP_EN(3) VP_EN(4) VP_EN(5) VP_EN(6) VP_EN(7)
+            VP_EN(8) VP_EN(9) VP_EN(10) VP_EN(11) VP_EN(12) VP_EN(13) VP_EN(14) VP_EN(15)
+#undef VP_EN
+        }
+        return r0;
+    }
+    const int n8 = n & ~7;
+    for (int i = 0; i < n8; i += 8) {
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = e0[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = a[u] * a[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) r0 += a[u];
+    }
+    for (int i = n8; i < n; i++) { double a = e0[i]; r0 += a * a; }
+    return r0;
+}
+
 // VocoderProcess::filterFIR (VocoderProcess.cpp:235-251) for one window by one wavefront:
 // e[i] = a[0]*xw[i] + sum_{k=1..min(order,i)} xw[i-k]*a[k].
 template <class XP, class AP, class EP>
@@ -809,10 +844,18 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         }
         __syncthreads();
         STAMP(d, 17);
-        if (active) {                                    // whole wavefront, coefficient vector over the lanes
-            lds_f64 *scr = (W >= 128) ? D : (lds_f64 *)nullptr;       // eVoice is not written yet: scratch
-            levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, scr);
-            levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, scr);
+        if (activeW && role < 2) {                       // whole wavefront, coefficient vector over the lanes
+            // eVoice is not written yet: scratch (128 doubles each; the carrier's recursion runs beside the voice's on
+            // the window's second wavefront when it has one)
+            lds_f64 *scr = (W >= 128) ? D : (lds_f64 *)nullptr;
+            lds_f64 *scr2 = (W >= 256) ? D + 128 : (lds_f64 *)nullptr;
+            if (nRoles == 1) {
+                levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, scr);
+                levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, scr);
+            } else if (role == 0)
+                levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, scr);
+            else
+                levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, scr2);
         }
         __syncthreads();
         STAMP(d, 18);
@@ -833,10 +876,18 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         }
         __syncthreads();
         STAMP(d, 19);
-        if (active) {                                    // E += e[i]*e[i], left to right (:250)
-            double Ev, Es;
-            energy_pair_wave(D, A, W, Ev, Es);
-            if (lane == 0) { roundE[wave] = Ev; roundE[8 + wave] = Es; }
+        if (activeW && role < 2) {                       // E += e[i]*e[i], left to right (:250)
+            if (nRoles == 1) {
+                double Ev, Es;
+                energy_pair_wave(D, A, W, Ev, Es);
+                if (lane == 0) { roundE[wave] = Ev; roundE[8 + wave] = Es; }
+            } else if (role == 0) {                      // one sum per wavefront
+                const double Ev = energy_wave(D, W);
+                if (lane == 0) roundE[wave] = Ev;
+            } else {
+                const double Es = energy_wave(A, W);
+                if (lane == 0) roundE[8 + wave] = Es;
+            }
         }
         __syncthreads();
         STAMP(d, 20);
