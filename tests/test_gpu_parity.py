@@ -1006,3 +1006,53 @@ def test_mono_entry_device_and_multi_block_forms():
         y = dout8.cpu().numpy()
         for j in range(8):
             _assert_equal(y[j], ref[:, :, (b0 + j) * N:(b0 + j + 1) * N], f"mono multi block {b0 + j}")
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_randomised_configurations_with_extensions_bit_exact(seed):
+    """The randomised sweep again with this round's additions switched on at random: per-stream fixed pitch shifts
+    (set, changed and switched off between blocks), mono and three-channel calls mixed, block by block against one
+    oracle per stream.  (The vocoder's several-wavefronts-per-window launch comes in through the small block sizes.)"""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    fs, N, params = _fuzz_case(2000 + seed)
+    rng = np.random.default_rng(7000 + seed)
+    S = 4
+    T = max(8, int(24000 * fs / 44100.0) // N) * N
+    x = _streams(S, T, fs=fs)
+    p = BatchVocoderProcessor(**params)
+    try:
+        p.prepareToPlay(fs, N, S)
+    except VpError as e:
+        assert e.code == -4, e
+        pytest.skip(f"geometry for fs={fs} exceeds the LDS budget (VP_ERR_GEOMETRY)")
+    os_ = []
+    for s_ in range(S):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(fs, N)
+        os_.append(o)
+    nb = T // N
+    for b in range(nb):
+        if rng.random() < 0.25:                                      # a shift event on a random stream
+            s_ = int(rng.integers(0, S))
+            on = rng.random() < 0.8
+            semi = float(rng.choice([-12.0, -7.0, -2.5, 0.0, 3.0, 5.0, 12.0]))
+            try:
+                p.setPitchShift(semi, on=on, stream=s_)
+            except VpError as e:
+                assert e.code == -4, e                               # more synthesis marks than the arrays hold: refused
+            else:
+                os_[s_].set_pitch_shift(semi, on=on)
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        mono = rng.random() < 0.4
+        got = p.process_mono(np.ascontiguousarray(blk[:, 0])) if mono else p.process(blk)
+        for s_ in range(S):
+            if mono:
+                ref = os_[s_].process_block_mono(np.ascontiguousarray(blk[s_, 0]))
+            else:
+                io = blk[s_].copy()
+                os_[s_].process_block(io)
+                ref = io[:2]
+            _assert_equal(got[s_], ref, f"seed {seed}: fs={fs} N={N} {params} block {b} mono={mono} stream {s_}")
+    ub = np.sum([o.ub_counters() for o in os_], axis=0)
+    assert list(p.ub_counters()) == list(ub)
