@@ -1056,3 +1056,28 @@ def test_randomised_configurations_with_extensions_bit_exact(seed):
             _assert_equal(got[s_], ref, f"seed {seed}: fs={fs} N={N} {params} block {b} mono={mono} stream {s_}")
     ub = np.sum([o.ub_counters() for o in os_], axis=0)
     assert list(p.ub_counters()) == list(ub)
+
+
+@pytest.mark.parametrize("params,N", [(dict(), 1024), (dict(pitchBool=0, lpcVoice=64, lpcSynth=30), 1024), (dict(pitchBool=0), 300)])
+def test_register_light_vocoder_for_large_batches(params, N):
+    """Above 256 streams in FAST IIR mode the host launches vp_k_vocoder_lite: half the window slots, two wavefronts per
+    slot, two workgroups per CU.  Same arithmetic as the regular FAST vocoder: the streams must come out bit-identical
+    to what a small batch (regular build) gives, and within the stated tolerance of the oracle."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, B = 300, 8
+    x = _streams(S, N * B)
+
+    def run(xs):
+        p = BatchVocoderProcessor(**params)
+        p.prepareToPlay(FS, N, xs.shape[0])
+        p.set_iir_mode("fast")
+        return p.run(xs)
+
+    big = run(x)
+    pick = [0, 7, 255, 256, 299]
+    small = run(np.ascontiguousarray(x[pick]))                       # <= 256 streams: vp_k_vocoder
+    _assert_equal(big[pick], small, "lite vs regular FAST vocoder")
+    ref = _oracle_run(x[pick], N, params)
+    err = big[pick].astype(np.float64) - ref
+    assert np.sqrt((err ** 2).mean()) < RMS_TOL
+    assert np.abs(ref).max() > 0.02

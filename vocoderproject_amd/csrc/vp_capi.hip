@@ -443,7 +443,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c,
-                             (const void *)vp_k_vocoder};
+                             (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
             HIPCHK(h, hipFuncGetAttributes(&fa, f));                        // the static part (a few reduction slots) comes off the top
@@ -610,10 +610,18 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             ProfScope ps(h, st, 1);
             int nw = std::min(h->vocWaves, c.nWin);
             if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
+            // large batches, FAST IIR: the register-light build with half the window slots, so that two workgroups share a
+            // CU (each slot then has two wavefronts; needs <= 80 KB of LDS per workgroup)
+            bool lite = g.S > 256 && cv.iirFast && !getenv("VP_VOC_NO_LITE");
+            if (lite) {
+                int nl = std::max(1, std::min(nw, 4));
+                while (nl > 1 && vp_voc_lds_bytes(g.W, nl) > (size_t)(80 * 1024 - 512)) nl--;
+                if (vp_voc_lds_bytes(g.W, nl) <= (size_t)(80 * 1024 - 512)) nw = nl; else lite = false;
+            }
             cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
             cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
             const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
-            hipLaunchKernelGGL(vp_k_vocoder, dim3(g.S), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
+            hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : vp_k_vocoder, dim3(g.S), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
         }
         if (runPitch) {
             VpCall cp = c;

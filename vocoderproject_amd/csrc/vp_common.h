@@ -102,6 +102,6 @@ __host__ __device__
 #endif
 static inline size_t voc_wave_doubles(int W)
 {
-    return (size_t)4 * W + 3 * (VP_ORDER_MAX + 1) + 3 * (VP_ORDER_MAX_SYNTH + 1) + 4;
+    return (size_t)4 * W + 2 * (VP_ORDER_MAX + 1) + 2 * (VP_ORDER_MAX_SYNTH + 1) + 2;    // A B Cc D | rV aV | rS aS | pad (even: 16-byte alignment)
 }
 #define VP_VOC_SHARED_DOUBLES(W) ((size_t)(W) + 20 + 16 + 8)

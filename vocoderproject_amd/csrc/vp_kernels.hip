@@ -756,8 +756,11 @@ __device__ __forceinline__ void iir_block_wave_regs(const lds_f64 *x, lds_f64 *y
 //   B  [W] f64   first: xwV = voice*anWindow; later: out (IIR output, then scaled for the OLA)
 //   Cc [W] f64   xwS = synth*anWindow
 //   D  [W] f64   eVoice (only its energy is used)
-//   r/a/aPrev for voice (101 each) and synth (31 each), energies
+//   r/a for voice (101 each) and synth (31 each)
 
+// LITE: the build for two workgroups per CU (<= 128 VGPRs, FAST IIR only -- the register-resident exact recursion is
+// compiled out; the host never launches it in exact mode).
+template <bool LITE>
 __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, const VpDev &d, double *smem)
 {
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -780,8 +783,8 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
     lds_f64 *wbase = gArr + 8 + (size_t)wave * voc_wave_doubles(W);
     lds_f64 *A = wbase, *B = A + W, *Cc = B + W, *D = Cc + W;
     lds_f32 *xv = (lds_f32 *)A, *xsy = xv + W;
-    lds_f64 *rV = D + W, *aV = rV + (VP_ORDER_MAX + 1), *aPV = aV + (VP_ORDER_MAX + 1);
-    lds_f64 *rS = aPV + (VP_ORDER_MAX + 1), *aS = rS + (VP_ORDER_MAX_SYNTH + 1);
+    lds_f64 *rV = D + W, *aV = rV + (VP_ORDER_MAX + 1);
+    lds_f64 *rS = aV + (VP_ORDER_MAX + 1), *aS = rS + (VP_ORDER_MAX_SYNTH + 1);
 
     for (int i = tid; i < W; i += blockDim.x) win[i] = d.vocWin[i];
     if (tid < 20) hist[tid] = d.EeArr[(size_t)s * 20 + tid];
@@ -918,7 +921,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         // The chain code must run with EVERY lane of the wave active: executed under a one-lane
         // EXEC mask it is slower and, worse, chains in different waves then serialise (measured,
         // tools/ubench_iir.hip modes 1 vs 3).  Spare lanes redo the last window (identical stores).
-        if (c.iirFast) {
+        if (LITE || c.iirFast) {
             if (active) iir_fast_wave(A, B, W, aV, oV, (const lds_f64 *)nullptr, gArr[wave]);   // wave per window, lanes over taps
         } else if (waveHw == 0) {
             const int wj = min(lane, nAct - 1);
@@ -966,7 +969,18 @@ __global__ __launch_bounds__(512) void vp_k_vocoder(VpGeom g, VpCall c, VpDev d,
     extern __shared__ double smem[];
     VP_POISON(smem, c.ldsBytes);
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);
-    vocoder_block(g, c, d, smem);
+    vocoder_block<false>(g, c, d, smem);
+    if (c.fuseEmit) {
+        __syncthreads();
+        emit_block(g, c, d, out);
+    }
+}
+__global__ __launch_bounds__(512, 4) void vp_k_vocoder_lite(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    VP_POISON(smem, c.ldsBytes);
+    if (c.fuseIngest) ingest_gate_block(g, c, d, in);
+    vocoder_block<true>(g, c, d, smem);
     if (c.fuseEmit) {
         __syncthreads();
         emit_block(g, c, d, out);
