@@ -191,6 +191,8 @@ const char *vp_kernel_slot_name(int slot);
 /* Symbol of the pitch-kernel build the handle's current geometry and modes select (slot 2 is one of
  * vp_k_pitch[_fast][_c], vp_k_pitch_lite[_fast], vp_k_pitch[_fast]_fft; _c = the common-case builds); "" before prepare. */
 const char *vp_pitch_kernel_name(const vp_handle *h);
+/* Likewise for slot 1: vp_k_vocoder, or vp_k_vocoder_lite (FAST IIR, more than 256 streams: two workgroups per CU). */
+const char *vp_vocoder_kernel_name(const vp_handle *h);
 
 /* Counts, over all streams since prepare, how often a kernel reached one of the reference's
  * undefined-behaviour sites (back() of an empty vector, yinTemp[tauMax]):

@@ -1070,7 +1070,9 @@ def test_register_light_vocoder_for_large_batches(params, N):
     def run(xs):
         p = BatchVocoderProcessor(**params)
         p.prepareToPlay(FS, N, xs.shape[0])
+        assert p.vocoder_kernel_name() == "vp_k_vocoder"              # exact IIR: always the regular build
         p.set_iir_mode("fast")
+        assert p.vocoder_kernel_name() == ("vp_k_vocoder_lite" if xs.shape[0] > 256 else "vp_k_vocoder")
         return p.run(xs)
 
     big = run(x)

@@ -105,6 +105,22 @@ extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
     return lite ? (fast ? "vp_k_pitch_lite_fast" : "vp_k_pitch_lite") : (fast ? "vp_k_pitch_fast" : "vp_k_pitch");
 }
 
+// vp_k_vocoder_lite (FAST IIR only, <= 128 VGPRs): above 256 streams, with at most four window slots so that two
+// workgroups share a CU (<= 80 KB of LDS each).  Returns the slots to use, 0 = the regular build.
+static int voc_lite_slots(const vp_handle *h, bool iirFast, int nw)
+{
+    if (!(h->g.S > 256 && iirFast) || getenv("VP_VOC_NO_LITE")) return 0;
+    int nl = std::max(1, std::min(nw, 4));
+    while (nl > 1 && vp_voc_lds_bytes(h->g.W, nl) > (size_t)(80 * 1024 - 512)) nl--;
+    return vp_voc_lds_bytes(h->g.W, nl) <= (size_t)(80 * 1024 - 512) ? nl : 0;
+}
+
+extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
+{
+    if (!h || !h->prepared) return "";
+    return voc_lite_slots(h, h->iirMode == VP_IIR_FAST, h->vocWaves) ? "vp_k_vocoder_lite" : "vp_k_vocoder";
+}
+
 extern "C" const char *vp_kernel_slot_name(int slot)
 {
     static const char *n[VP_NUM_KERNEL_SLOTS] = {"vp_k_ingest_gate", "vp_k_vocoder", "vp_k_pitch", "vp_k_emit"};
@@ -612,12 +628,9 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
             // large batches, FAST IIR: the register-light build with half the window slots, so that two workgroups share a
             // CU (each slot then has two wavefronts; needs <= 80 KB of LDS per workgroup)
-            bool lite = g.S > 256 && cv.iirFast && !getenv("VP_VOC_NO_LITE");
-            if (lite) {
-                int nl = std::max(1, std::min(nw, 4));
-                while (nl > 1 && vp_voc_lds_bytes(g.W, nl) > (size_t)(80 * 1024 - 512)) nl--;
-                if (vp_voc_lds_bytes(g.W, nl) <= (size_t)(80 * 1024 - 512)) nw = nl; else lite = false;
-            }
+            const int nl = voc_lite_slots(h, cv.iirFast != 0, nw);
+            const bool lite = nl > 0;
+            if (lite) nw = nl;
             cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
             cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
             const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8

@@ -93,6 +93,9 @@ def load_library():
         L.vp_get_pitch_shift.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.vp_pitch_kernel_name.argtypes = [C.c_void_p]
     L.vp_pitch_kernel_name.restype = C.c_char_p
+    if hasattr(L, "vp_vocoder_kernel_name"):
+        L.vp_vocoder_kernel_name.argtypes = [C.c_void_p]
+        L.vp_vocoder_kernel_name.restype = C.c_char_p
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
     L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vp_set_yin_mode.argtypes = [vp, C.c_int]
@@ -346,6 +349,9 @@ class BatchVocoderProcessor:
 
     def pitch_kernel_name(self):
         return self.L.vp_pitch_kernel_name(self.h).decode()
+
+    def vocoder_kernel_name(self):
+        return self.L.vp_vocoder_kernel_name(self.h).decode()
 
 
 class StftRoundTrip:
