@@ -1083,3 +1083,41 @@ def test_register_light_vocoder_for_large_batches(params, N):
     err = big[pick].astype(np.float64) - ref
     assert np.sqrt((err ** 2).mean()) < RMS_TOL
     assert np.abs(ref).max() > 0.02
+
+
+@pytest.mark.parametrize("S,iir", [(1024, "exact"), (1024, "fast"), (4096, "fast")])
+def test_config3_scale_batches(S, iir):
+    """BASELINE configs[3] per GPU (1024 streams, pitch corrector + vocoder) and four times that: sampled streams against
+    the oracle (bit-exact in exact mode, within tolerance in FAST mode, where the large-batch builds of both kernels
+    run), and a size-independent property at full size: permuting the streams of the batch permutes the output."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    N, B, U = 1024, 5, 16
+    base = _streams(U, N * B)
+    idx = np.arange(S) % U
+    x = np.ascontiguousarray(base[idx])
+
+    def run(xs):
+        p = BatchVocoderProcessor()
+        p.prepareToPlay(FS, N, xs.shape[0])
+        p.set_iir_mode(iir)
+        if iir == "fast":
+            assert p.vocoder_kernel_name() == "vp_k_vocoder_lite" and p.pitch_kernel_name().startswith("vp_k_pitch_lite")
+        return p.run(xs)
+
+    got = run(x)
+    ref = _oracle_run(base, N, {})
+    pick = [0, 1, U + 3, S // 2 + 5, S - 1]
+    if iir == "exact":
+        for s_ in pick:
+            _assert_equal(got[s_], ref[idx[s_]], f"stream {s_}")
+        # every copy of a stream comes out the same, wherever it sits in the batch
+        for u in range(U):
+            assert np.all(got[u::U] == got[u]), u
+    else:
+        err = got[pick].astype(np.float64) - ref[idx[pick]]
+        assert np.sqrt((err ** 2).mean()) < RMS_TOL
+        for u in range(U):
+            assert np.all(got[u::U] == got[u]), u
+    perm = np.random.default_rng(S).permutation(S)
+    got_p = run(np.ascontiguousarray(x[perm]))
+    np.testing.assert_array_equal(got_p, got[perm])
