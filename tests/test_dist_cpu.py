@@ -70,3 +70,35 @@ def test_two_rank_shard_process_gather_matches_single_process(S):
         ref[s] = o.run(np.ascontiguousarray(x[s]))
     np.testing.assert_array_equal(y, ref)
     assert np.abs(ref).max() > 0.01
+
+
+def _subgroup_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vocoderproject_amd.dist import gather_streams, scatter_streams
+        grp = dist.new_group([1, 2])                     # group ranks 0, 1 are GLOBAL ranks 1, 2
+        if rank in (1, 2):
+            S = 5
+            x_root = torch.arange(S * 4, dtype=torch.float32).view(S, 4) if rank == 1 else None
+            mine = scatter_streams(x_root, S, (4,), torch.float32, "cpu", src=0, group=grp)
+            lo, hi = shard_range(S, dist.get_rank(grp), 2)
+            assert torch.equal(mine, torch.arange(S * 4, dtype=torch.float32).view(S, 4)[lo:hi])
+            full = gather_streams(mine * 2, S, dst=1, group=grp)      # gather on the OTHER member (global rank 2)
+            if rank == 2:
+                ret["y"] = full.numpy().copy()
+            else:
+                assert full is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scatter_gather_inside_a_subgroup_uses_group_ranks():
+    """src/dst are ranks of `group`; the point-to-point calls need global ranks."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(3, port, ret), nprocs=3, join=True)
+    np.testing.assert_array_equal(ret["y"], 2 * np.arange(20, dtype=np.float32).reshape(5, 4))

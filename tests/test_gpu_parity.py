@@ -467,7 +467,7 @@ def test_register_light_kernel_variant_for_large_batches():
 
 def _fuzz_case(seed):
     rng = np.random.default_rng(seed)
-    fs = float(rng.choice([22050.0, 32000.0, 44100.0, 48000.0, 44099.0, 88200.0]))
+    fs = float(rng.choice([8000.0, 11025.0, 16000.0, 22050.0, 32000.0, 44100.0, 48000.0, 44099.0, 88200.0]))
     N = int(rng.choice([64, 100, 278, 441, 512, 1000, 1024, 1536, 3000]))
     params = dict(lpcVoice=int(rng.integers(2, 101)), lpcPitch=int(rng.integers(2, 101)), lpcSynth=int(rng.integers(2, 31)),
                   keyPitch=int(rng.integers(0, 13)), gainPitch=float(rng.uniform(-20, 6)), gainVoc=float(rng.uniform(-20, 6)),
@@ -588,7 +588,7 @@ def test_per_stream_parameters():
         os_.append(o)
     assert p.getStreamParameter(1, "keyPitch") == 3 and p.getStreamParameter(0, "keyPitch") == 12
     with pytest.raises(VpError):
-        p.setStreamParameter(0, "pitchBool", 0)                     # per handle only
+        p.setStreamParameter(0, "lpcPitch", 20)                     # per handle only (read at prepare, selects the kernel build)
     with pytest.raises(VpError):
         p.setStreamParameter(S, "keyPitch", 1)                      # no such stream
     for b in range(B):

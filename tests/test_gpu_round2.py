@@ -1,0 +1,300 @@
+"""GPU parity tests added in round 2 (through the C ABI, against the CPU oracle on identical inputs):
+per-stream pitchBool/vocBool (PluginProcessor.cpp:214-221), ScopedNoDenormals (:205), multi-block launches with host
+blocks smaller than the chunk, low sample rates (LDS scratch sizing), STFT geometry validation, and the
+scatter/gather helpers over backend nccl (= RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FS = 44100.0
+
+
+def _streams(S, T, **kw):
+    from vocoderproject_amd.synth import make_streams
+    return np.ascontiguousarray(make_streams(S, T, **kw).numpy())
+
+
+def _assert_equal(got, ref, what=""):
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"{what}: {len(bad)} samples differ, first at {bad[0]}, max abs {np.abs(got - ref).max()}"
+
+
+# ---- per-stream pitchBool / vocBool ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,iir", [(1024, "exact"), (300, "exact"), (1024, "fast")])
+def test_per_stream_switches_mixed_batch(N, iir):
+    """Every stream is its own plugin instance with its own pitchBool / vocBool (PluginProcessor.cpp:214-221): a process
+    that is switched off does not advance its startSample / nChunk, pitchBool off calls silence().  Streams are switched
+    at different blocks, so their window and chunk grids drift apart; each must equal its own oracle instance."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, B = 7, 40 if N == 1024 else 90
+    x = _streams(S, N * B)
+    init = [dict(), dict(pitchBool=0), dict(vocBool=0), dict(pitchBool=0, vocBool=0), dict(), dict(vocBool=0), dict(pitchBool=0)]
+    sched = {3: (4, "vocBool", 0), 5: (1, "pitchBool", 1), 8: (4, "vocBool", 1), 9: (2, "vocBool", 1), 11: (3, "pitchBool", 1),
+             14: (0, "pitchBool", 0), 15: (3, "vocBool", 1), 17: (0, "pitchBool", 1), 20: (5, "pitchBool", 0), 22: (6, "keyPitch", 3),
+             23: (5, "pitchBool", 1), 27: (2, "pitchBool", 0), 31: (2, "pitchBool", 1)}
+    p = BatchVocoderProcessor()
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode(iir)
+    os_ = []
+    for s_, kv in enumerate(init):
+        o = O.OracleStream()
+        o.prepare_to_play(FS, N)
+        for k, v in kv.items():
+            p.setStreamParameter(s_, k, v)
+            o.set_param(k, v)
+        os_.append(o)
+    worst = 0.0
+    for b in range(B):
+        if b in sched:
+            s_, k, v = sched[b]
+            p.setStreamParameter(s_, k, v)
+            os_[s_].set_param(k, v)
+        if b == 34:                                                   # handle-wide set: one set of switches again, grids stay apart
+            p.setParameter("vocBool", 1)
+            for o in os_:
+                for k, v in dict(pitchBool=1, vocBool=1, keyPitch=12).items():
+                    o.set_param(k, v)
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        got = p.process(blk)
+        for s_ in range(S):
+            io = blk[s_].copy()
+            os_[s_].process_block(io)
+            if iir == "exact":
+                _assert_equal(got[s_], io[:2], f"block {b} stream {s_}")
+            else:
+                worst = max(worst, float(np.sqrt(np.mean((got[s_].astype(np.float64) - io[:2]) ** 2))))
+    if iir == "fast":
+        assert worst < 1e-4, worst                                    # north_star's tolerance (per-sample RMS)
+    ub = np.sum([o.ub_counters() for o in os_], axis=0)
+    assert list(p.ub_counters()) == list(ub)
+
+
+def test_per_stream_switches_large_batch_cohorts():
+    """The same on a batch large enough for the register-light builds, with two cohorts of very different size."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 300, 1024, 10
+    x = _streams(S, N * B)
+    p = BatchVocoderProcessor()
+    p.prepareToPlay(FS, N, S)
+    odd = [5, 77, 299]
+    for s_ in odd:
+        p.setStreamParameter(s_, "vocBool", 0)
+    ys = []
+    for b in range(B):
+        if b == 4:
+            p.setStreamParameter(77, "vocBool", 1)
+            p.setStreamParameter(8, "pitchBool", 0)
+        ys.append(p.process(np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])))
+    got = np.concatenate(ys, axis=2)
+    for s_ in (0, 5, 8, 77, 150, 299):
+        o = O.OracleStream()
+        o.prepare_to_play(FS, N)
+        if s_ in odd:
+            o.set_param("vocBool", 0)
+        ref = []
+        for b in range(B):
+            if b == 4 and s_ == 77:
+                o.set_param("vocBool", 1)
+            if b == 4 and s_ == 8:
+                o.set_param("pitchBool", 0)
+            io = np.ascontiguousarray(x[s_, :, b * N:(b + 1) * N]).copy()
+            o.process_block(io)
+            ref.append(io[:2])
+        _assert_equal(got[s_], np.concatenate(ref, axis=1), f"stream {s_}")
+
+
+# ---- ScopedNoDenormals ----------------------------------------------------------------------------------------------
+
+def test_denormal_inputs_and_outputs_flush_like_scoped_no_denormals():
+    """PluginProcessor.cpp:205: processBlock runs with FTZ|DAZ.  f32-denormal input samples enter as 0.0 and results in
+    the f32-denormal range leave as 0.0f; the kernels are built with the matching denormal mode.  Dry voice/carrier on,
+    so input samples reach the output directly."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B = 4, 1024, 24
+    T = N * B
+    x = _streams(S, T)
+    rng = np.random.default_rng(7)
+    den = (10.0 ** rng.uniform(-45, -38.2, size=T)).astype(np.float32) * rng.choice([-1.0, 1.0], size=T).astype(np.float32)
+    assert np.count_nonzero((np.abs(den) > 0) & (np.abs(den) < 1.1754944e-38)) > T // 2
+    # stream 0: nothing but denormals (gate closed: only the dry paths speak)
+    x[0, 0] = den; x[0, 1] = den[::-1]; x[0, 2] = -den
+    # stream 1: a normal voice with every 5th sample replaced by a denormal, carrier decaying through the denormal range
+    x[1, 0, ::5] = den[::5]
+    decay = (0.3 * np.exp(-np.arange(T) / 180.0)).astype(np.float32)
+    x[1, 1] = decay; x[1, 2] = decay * np.float32(0.5)
+    x[1, 0, 14000:] = 0.0                                            # the voice stops: the carrier's denormal tail is alone in the output
+    # stream 2: the voice fades out into the denormal range and comes back (gate crossings on the way)
+    env = np.exp(-np.abs(((np.arange(T) % 12000) - 6000)) / 60.0).astype(np.float64)
+    x[2, 0] = (x[2, 0].astype(np.float64) * (1.0 - env) * 1e-3 + 1e-41 * np.sin(np.arange(T))).astype(np.float32)
+    params = dict(gainVoice=0.0, gainSynth=-1.0, gainPitch=-3.0)
+    p = BatchVocoderProcessor(**params)
+    p.prepareToPlay(FS, N, S)
+    got = p.run(x)
+    ref, raw = [], []
+    for s_ in range(S):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(FS, N)
+        ref.append(o.run(x[s_]))
+        o2 = O.OracleStream(**params)                                   # the same WITHOUT flushing: must differ, or the test is vacuous
+        o2.prepare_to_play(FS, N)
+        o2.set_ftz(False)
+        raw.append(o2.run(x[s_]))
+    ref, raw = np.stack(ref), np.stack(raw)
+    assert not np.array_equal(ref[0], raw[0]) and not np.array_equal(ref[1], raw[1])
+    _assert_equal(got, ref, "denormal inputs")
+    tiny = (np.abs(got) > 0) & (np.abs(got) < 1.1754944e-38)
+    assert not tiny.any()                                             # nothing denormal leaves
+    assert np.abs(got[3]).max() > 0.05
+
+
+# ---- multi-block launches with host blocks smaller than the chunk ------------------------------------------------------
+
+@pytest.mark.parametrize("N", [64, 100, 128])
+def test_multi_block_launch_with_blocks_smaller_than_the_chunk(N):
+    """with N < C a launch of several blocks can start on a block that has no chunk step of its own; every
+    block of the launch must still be ingested, processed and emitted."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    S = 4
+    B = (1024 * 14) // N
+    x = _streams(S, N * B)
+    xb = torch.from_numpy(np.ascontiguousarray(x.reshape(S, 3, B, N).transpose(2, 0, 1, 3))).cuda()      # [B][S][3][N]
+
+    def run(split):
+        p = BatchVocoderProcessor(vocBool=0)
+        p.prepareToPlay(FS, N, S)
+        y = torch.full((B, S, 2, N), float("nan"), dtype=torch.float32, device="cuda")
+        b = 0
+        for n in split:
+            p.process_blocks_device(xb[b:b + n].contiguous(), y[b:b + n])
+            b += n
+        assert b == B
+        torch.cuda.synchronize()
+        return y.cpu().numpy().transpose(1, 2, 0, 3).reshape(S, 2, B * N)
+
+    from oracle import oracle_py as O
+    ref = []
+    for s_ in range(S):
+        o = O.OracleStream(vocBool=0)
+        o.prepare_to_play(FS, N)
+        ref.append(o.run(x[s_]))
+    ref = np.stack(ref)
+    splits = [[1] * B, [3] * (B // 3) + [B % 3] * (1 if B % 3 else 0), [7, 2, 5] * (B // 14) + [B - 14 * (B // 14)] * (1 if B % 14 else 0), [B]]
+    for split in splits:
+        split = [n for n in split if n > 0]
+        _assert_equal(run(split), ref, f"N={N} split {split[:6]}...")
+
+
+# ---- low sample rates: the scratch that lives in the yinTemp / running-sum LDS regions -----------------------------------
+
+@pytest.mark.parametrize("fs,N,prepare,params", [
+    (8000.0, 256, None, dict()),
+    (11025.0, 256, None, dict()),                                            # C = 64, tauMax = 111: common-case build
+    (11025.0, 64, None, dict(vocBool=0)),
+    (16000.0, 512, None, dict()),
+    (16000.0, 256, (16000.0, 256, 512, 384, 256, 64), dict()),               # explicit: C = 128
+    (9000.0, 200, None, dict(lpcPitch=100, lpcVoice=60)),                     # order above tauMax + 1
+    (12000.0, 128, (12000.0, 128, 256, 192, 128, 32), dict(lpcPitch=30)),
+])
+@pytest.mark.parametrize("iir", ["exact", "fast"])
+def test_low_sample_rates(fs, N, prepare, params, iir):
+    """at low sample rates tauMax + 1 is smaller than the scratch parked in the yinTemp / running-sum regions
+    (grain table, recursion history, block-form IIR impulse response); they are now sized for it."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S = 3
+    T = max(8, int(3.0 * fs) // N) * N
+    x = _streams(S, T, fs=fs)
+    p = BatchVocoderProcessor(**params)
+    if prepare:
+        p.prepareExplicit(prepare[0], prepare[1], S, *prepare[2:])
+    else:
+        p.prepareToPlay(fs, N, S)
+    p.set_iir_mode(iir)
+    got = p.run(x)
+    ref = []
+    for s_ in range(S):
+        o = O.OracleStream(**params)
+        if prepare:
+            o.prepare_explicit(*prepare)
+        else:
+            o.prepare_to_play(fs, N)
+        ref.append(o.run(x[s_]))
+    ref = np.stack(ref)
+    assert np.abs(ref).max() > 0.02
+    if iir == "exact":
+        _assert_equal(got, ref, f"fs={fs} N={N} {params} [{p.pitch_kernel_name()}]")
+    else:
+        rms = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
+        assert rms < 1e-4, (rms, p.pitch_kernel_name())              # north_star's tolerance
+        st = [p.pitch_state(s_) for s_ in range(S)]
+        assert all(np.isfinite(s_["a"]).all() for s_ in st)
+
+
+# ---- STFT geometry validation -----------------------------------------------------------------------------------------
+
+def test_stft_geometry_validation_and_largest_frame():
+    import torch
+    from vocoderproject_amd import StftRoundTrip, VpError
+    with pytest.raises(VpError) as e:
+        StftRoundTrip(2, 4096, 1024, 1024)                           # hop == frame: no overlap to normalise
+    assert e.value.code == -4
+    T = 4096 * 6
+    st = StftRoundTrip(2, T, 4096, 1024)                              # 96 KB of dynamic LDS
+    x = torch.randn((2, T), dtype=torch.float32, device="cuda") * 0.1
+    y = torch.empty_like(x)
+    st(x, y)
+    torch.cuda.synchronize()
+    a, b = x.cpu().numpy()[:, 4096:-4096], y.cpu().numpy()[:, 4096:-4096]
+    assert np.abs(a - b).max() < 1e-5
+
+
+# ---- RCCL: scatter / gather over backend nccl ---------------------------------------------------------------------------
+
+def test_scatter_gather_over_nccl_world_size_1():
+    """the root fan-out / fan-in helpers over torch.distributed backend "nccl" (= RCCL).  One GPU per box
+    here, so world_size = 1: the process group is real RCCL, the exchange degenerates to the local copy."""
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    from vocoderproject_amd.dist import gather_streams, scatter_streams
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        S, N, B = 5, 1024, 10
+        x = _streams(S, N * B)
+        xr = torch.from_numpy(x).to(dev)
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)                                            # RCCL really up
+        assert float(t.item()) == 1.0
+        p = BatchVocoderProcessor()
+        p.prepareToPlay(FS, N, S)
+        outs = []
+        for b in range(B):
+            mine = scatter_streams(xr[:, :, b * N:(b + 1) * N].contiguous(), S, (3, N), torch.float32, dev)
+            y = torch.empty((S, 2, N), dtype=torch.float32, device=dev)
+            p.process_device(mine, y)
+            outs.append(gather_streams(y, S).cpu().numpy())
+        got = np.concatenate(outs, axis=2)
+    finally:
+        dist.destroy_process_group()
+    ref = []
+    for s_ in range(S):
+        o = O.OracleStream()
+        o.prepare_to_play(FS, N)
+        ref.append(o.run(x[s_]))
+    _assert_equal(got, np.stack(ref), "nccl world 1")

@@ -4,6 +4,10 @@
 
 -ffp-contract=off is part of the numerics contract: the kernels reproduce the reference's IEEE
 double arithmetic operation by operation (no FMA contraction), see csrc/vp_kernels.hip.
+-fdenormal-fp-math=preserve-sign is the other part: the reference's processBlock() runs under
+juce::ScopedNoDenormals (PluginProcessor.cpp:205: MXCSR FTZ|DAZ for float AND double SSE arithmetic), so every
+kernel is built with the wave's denormal modes (float and double) set to "flush inputs and results": an f32-denormal
+input sample is widened to 0.0, a result in the f32-denormal range leaves as (signed) 0.0f, like on the CPU.
 """
 import os
 import shutil
@@ -49,7 +53,7 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     # vp_capi.hip is one more; then one link.  (One translation unit takes 90 s, the groups 40 s.)
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
-    common = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+    common = [hipcc(), "-std=c++17", "-O3", "-ffp-contract=off", "-fdenormal-fp-math=preserve-sign", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     common += os.environ.get("VP_EXTRA_HIPCC_FLAGS", "").split()     # experiments (tools/ab.sh): e.g. scheduler options
     if stamps:

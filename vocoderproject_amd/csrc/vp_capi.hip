@@ -26,8 +26,18 @@ struct vp_handle {
     vp_params params;
     VpGeom g;
     VpDev d;
-    // MyBuffer counters (MyBuffer.h:72-79), VocoderProcess::startSample, PitchProcess::startSample/nChunk
-    int inCounter = 0, outCounter = 0, currCounter = 0, vStart = 0, pStart = 0, nChunk = 0;
+    // MyBuffer counters (MyBuffer.h:72-79): every instance advances them by N per block whatever its switches
+    int inCounter = 0, outCounter = 0, currCounter = 0;
+    // VocoderProcess::startSample, PitchProcess::startSample/nChunk only advance while the instance's vocBool / pitchBool
+    // is on (PluginProcessor.cpp:214-221), so streams whose switches differ(ed) carry different values: the batch is
+    // kept as COHORTS of streams that share switches and counters.  One cohort holding every stream (dMap == nullptr)
+    // is the normal case and costs nothing; otherwise each cohort is launched on its own with a stream-index map.
+    struct Cohort { int pitchOn, vocOn, vStart, pStart, nChunk, n; int *dMap; std::vector<int> ids; };
+    std::vector<Cohort> cohorts;
+    bool cohortsDirty = false;                  // a set call changed some stream's pitchBool / vocBool
+    int *dMapAll = nullptr;                     // [S] device storage of the cohorts' maps, back to back
+    std::vector<int> mapHost;                   // staging for its upload
+    bool poisoned = false;                      // a HIP call failed inside a process call: host counters and device state may disagree
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
@@ -95,14 +105,27 @@ static bool pitch_common(const vp_handle *h)
     return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512;
 }
 
+// THE selection of the pitch-kernel build for a launch (used by the launch site and by vp_pitch_kernel_name alike)
+typedef void (*vp_dsp_kernel)(VpGeom, VpCall, VpDev, const float *, float *);
+struct PitchPlan { vp_dsp_kernel fn; const char *name; size_t lds; };
+#define VP_PLAN(K, LDS) PitchPlan{K, #K, LDS}
+static PitchPlan pitch_plan(const vp_handle *h, bool fast, bool fft, int nBlocks)
+{
+    const bool lite = pitch_lite(h, fast, fft), com = pitch_common(h);
+    const size_t lds = h->pitchLds;
+    if (fft) return fast ? VP_PLAN(vp_k_pitch_fast_fft, lds + vp_pitch_fft_lds_bytes(h->g)) : VP_PLAN(vp_k_pitch_fft, lds + vp_pitch_fft_lds_bytes(h->g));   // never `lite` (pitch_lite)
+    if (nBlocks > 1)                                      // never with `lite` (process_blocks_device)
+        return fast ? (com ? VP_PLAN(vp_k_pitch_fast_multi_c, lds) : VP_PLAN(vp_k_pitch_fast_multi, lds)) : VP_PLAN(vp_k_pitch_multi, lds);
+    if (lite) return fast ? (com ? VP_PLAN(vp_k_pitch_lite_fast_c, lds) : VP_PLAN(vp_k_pitch_lite_fast, lds)) : VP_PLAN(vp_k_pitch_lite, lds);
+    if (com) return fast ? VP_PLAN(vp_k_pitch_fast_c, lds) : VP_PLAN(vp_k_pitch_c, lds);
+    return fast ? VP_PLAN(vp_k_pitch_fast, lds) : VP_PLAN(vp_k_pitch, lds);
+}
+#undef VP_PLAN
+
 extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
-    const bool fast = h->iirMode == VP_IIR_FAST, lite = pitch_lite(h, fast, h->yinMode == VP_YIN_FFT);
-    if (h->yinMode == VP_YIN_FFT && h->g.fftLog > 0) return fast ? "vp_k_pitch_fast_fft" : "vp_k_pitch_fft";
-    if (!lite && pitch_common(h)) return fast ? "vp_k_pitch_fast_c" : "vp_k_pitch_c";
-    if (lite && fast && pitch_common(h)) return "vp_k_pitch_lite_fast_c";
-    return lite ? (fast ? "vp_k_pitch_lite_fast" : "vp_k_pitch_lite") : (fast ? "vp_k_pitch_fast" : "vp_k_pitch");
+    return pitch_plan(h, h->iirMode == VP_IIR_FAST, h->yinMode == VP_YIN_FFT && h->g.fftLog > 0, 1).name;
 }
 
 // vp_k_vocoder_lite (FAST IIR only, <= 128 VGPRs): above 256 streams, with at most four window slots so that two
@@ -168,7 +191,7 @@ static void free_all(vp_handle *h)
 {
     for (void *p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
-    h->stageIn = h->stageOut = nullptr;
+    h->stageIn = h->stageOut = nullptr; h->dMapAll = nullptr; h->cohorts.clear();
     if (h->stageInB) (void)hipFree(h->stageInB);
     if (h->stageOutB) (void)hipFree(h->stageOutB);
     h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
@@ -191,10 +214,12 @@ extern "C" int vp_destroy(vp_handle *h)
 extern "C" int vp_set_params(vp_handle *h, const vp_params *p)
 {
     if (!h || !p || !params_valid(p)) return VP_ERR_INVALID_ARG;
+    const bool sw = p->pitchBool != h->params.pitchBool || p->vocBool != h->params.vocBool || h->perStream;
     h->params = *p;
     h->perStream = false;                       // one set for every stream again
     for (auto &q : h->sparams) q = *p;
     h->spDirty = true;
+    if (sw) h->cohortsDirty = true;             // (the processes' counters stay where each stream left them)
     return VP_OK;
 }
 
@@ -205,11 +230,12 @@ extern "C" int vp_set_stream_params(vp_handle *h, int stream, const vp_params *p
     if (!h || !p || !params_valid(p)) return VP_ERR_INVALID_ARG;
     if (!h->prepared) return VP_ERR_NOT_PREPARED;
     if (stream < 0 || stream >= h->g.S) { h->lastError = "stream index out of range"; return VP_ERR_INVALID_ARG; }
-    // the switches that drive the (host-side) chunk and window schedulers, and the prepare-time order, are per handle
-    if (p->pitchBool != h->params.pitchBool || p->vocBool != h->params.vocBool || p->lpcPitch != h->params.lpcPitch) {
-        h->lastError = "pitchBool, vocBool and lpcPitch are per handle (vp_set_params); per-stream sets must repeat them";
+    // the prepare-time order is per handle (it selects the pitch kernel's build)
+    if (p->lpcPitch != h->params.lpcPitch) {
+        h->lastError = "lpcPitch is per handle (vp_set_params, read at prepare); per-stream sets must repeat it";
         return VP_ERR_INVALID_ARG;
     }
+    if (p->pitchBool != h->sparams[stream].pitchBool || p->vocBool != h->sparams[stream].vocBool) h->cohortsDirty = true;
     h->sparams[stream] = *p;
     h->perStream = true;
     h->spDirty = true;
@@ -497,6 +523,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         RC(dev_upload(h, &d.twRe, twr));
         RC(dev_upload(h, &d.twIm, twi));
     }
+    RC(dev_alloc(h, &h->dMapAll, (size_t)S));
     RC(dev_alloc(h, &h->stageIn, (size_t)S * 3 * N, false));
     RC(dev_alloc(h, &h->stageOut, (size_t)S * 3 * N, false));
     {   // PitchProcess::prepare initial members (:76-85): everything 0 except beta = 1
@@ -513,7 +540,9 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     h->inCounter = g.toKeep + g.latency;                                     // MyBuffer.cpp:60-62
     h->outCounter = 0;
     h->currCounter = g.toKeep;
-    h->vStart = 0; h->pStart = 0; h->nChunk = 0;                             // VocoderProcess.cpp:39, PitchProcess.cpp:85,90
+    // VocoderProcess.cpp:39, PitchProcess.cpp:85,90: startSample = 0, nChunk = 0 for every instance
+    h->cohorts.assign(1, vp_handle::Cohort{h->params.pitchBool, h->params.vocBool, 0, 0, 0, S, nullptr, {}});
+    h->cohortsDirty = false; h->poisoned = false;
     h->sparams.assign((size_t)S, h->params);                                 // prepare starts every stream from the handle's set
     h->spHost.assign((size_t)S, VpStreamParams{});
     h->synthNonZero = 0;                                                     // the rings start zeroed
@@ -570,29 +599,49 @@ static void fill_stream_params(VpStreamParams &o, const vp_params &P)
     o.gainSynth = (double)db_to_gain_f(P.gainSynth);
 }
 
-static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace, int nBlocks = 1, bool mono = false)
+// Streams are grouped by (pitchBool, vocBool, VocoderProcess::startSample, PitchProcess::startSample, nChunk): the
+// switches of a stream decide whether its two processes advance their counters in a block (PluginProcessor.cpp:214-221).
+// Called at the top of a process call when a set call touched a switch.
+static int rebuild_cohorts(vp_handle *h, hipStream_t st)
+{
+    const int S = h->g.S;
+    struct Key { int pitchOn, vocOn, vStart, pStart, nChunk; };
+    std::vector<Key> cur((size_t)S);
+    for (const auto &co : h->cohorts) {
+        const Key k{co.pitchOn, co.vocOn, co.vStart, co.pStart, co.nChunk};
+        if (!co.dMap) for (int i = 0; i < S; i++) cur[i] = k;
+        else for (int i : co.ids) cur[i] = k;
+    }
+    std::vector<vp_handle::Cohort> out;
+    for (int i = 0; i < S; i++) {
+        Key k = cur[i];
+        k.pitchOn = h->sparams[i].pitchBool; k.vocOn = h->sparams[i].vocBool;
+        vp_handle::Cohort *hit = nullptr;
+        for (auto &co : out)
+            if (co.pitchOn == k.pitchOn && co.vocOn == k.vocOn && co.vStart == k.vStart && co.pStart == k.pStart && co.nChunk == k.nChunk) { hit = &co; break; }
+        if (!hit) { out.push_back(vp_handle::Cohort{k.pitchOn, k.vocOn, k.vStart, k.pStart, k.nChunk, 0, nullptr, {}}); hit = &out.back(); }
+        hit->ids.push_back(i);
+    }
+    if (out.size() == 1) { out[0].ids.clear(); out[0].n = S; out[0].dMap = nullptr; }
+    else {
+        h->mapHost.clear();
+        for (auto &co : out) {
+            co.n = (int)co.ids.size();
+            co.dMap = h->dMapAll + h->mapHost.size();
+            h->mapHost.insert(h->mapHost.end(), co.ids.begin(), co.ids.end());
+        }
+        // (pageable source: the copy has left the host buffer when the call returns; stream-ordered in front of the launches)
+        HIPCHK(h, hipMemcpyAsync(h->dMapAll, h->mapHost.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    h->cohorts.swap(out);
+    h->cohortsDirty = false;
+    return VP_OK;
+}
+
+// What process_device does first: parameters that travel in device state, and the cohorts
+static int sync_stream_state(vp_handle *h, hipStream_t st)
 {
     const VpGeom &g = h->g;
-    const vp_params P = h->params;                                           // snapshot at call entry
-    h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;   // all kernels of every k-th call
-    if (P.lpcVoice > VP_ORDER_MAX || P.lpcSynth > VP_ORDER_MAX_SYNTH) return VP_ERR_ORDER;
-    VpCall c;
-    memset(&c, 0, sizeof c);
-    c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
-    c.pitchOn = P.pitchBool; c.vocOn = P.vocBool; c.inplace = inplace;
-    c.iirFast = h->iirMode;
-    c.nBlocks = 1;
-    // side-chain bus present or absent; the synth ring is written N samples per call, so after inSize samples of zeros
-    // (or straight after prepare) it holds nothing else and the mono path need not touch it
-    if (mono) {
-        c.inMono = h->synthNonZero > 0 ? 1 : 2;
-        h->synthNonZero = std::max(0, h->synthNonZero - g.N * nBlocks);
-    } else {
-        c.inMono = 0;
-        h->synthNonZero = g.inSize;
-    }
-    c.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
-    c.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
     if (h->spDirty) {
         // orders, key, gains and the dry-path switches travel in each stream's device state (VpPitchState::sp);
         // rewritten here, stream-ordered in front of this block's kernels, whenever a set call changed them
@@ -604,76 +653,114 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                                    sizeof(VpStreamParams), (size_t)g.S, hipMemcpyHostToDevice, st));
         h->spDirty = false;
     }
-    // VocoderProcess::process (VocoderProcess.cpp:173-183): windows while startSample < N
-    c.vStart = h->vStart;
-    c.nWin = 0;
-    if (c.vocOn && h->vStart < g.N) c.nWin = (g.N - h->vStart + g.h - 1) / g.h;
-    // PitchProcess::process (PitchProcess.cpp:166-196): chunk steps while startSample < N
-    c.pStart = h->pStart; c.nChunk0 = h->nChunk;
-    c.nSteps = 0;
-    if (c.pitchOn && h->pStart < g.N) c.nSteps = (g.N - h->pStart + g.C - 1) / g.C;
+    if (h->cohortsDirty) return rebuild_cohorts(h, st);
+    return VP_OK;
+}
 
-    // Kernel plan: ingest+gate runs as the prologue of the first DSP kernel and emit as the epilogue of
-    // the last one (all stages are one-workgroup-per-stream); they only stand alone when no DSP kernel runs.
-    const bool runVoc = c.nWin > 0, runPitch = c.nSteps > 0;
-    if (!runVoc && !runPitch) {
-        { ProfScope ps(h, st, 0); hipLaunchKernelGGL(vp_k_ingest_gate, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_in); }
-        { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(g.S), dim3(256), 0, st, g, c, h->d, d_out); }
+static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace, int nBlocks = 1, bool mono = false)
+{
+    const VpGeom &g = h->g;
+    if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
+    const vp_params P = h->params;                                           // snapshot at call entry
+    h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;   // all kernels of every k-th call
+    if (P.lpcVoice > VP_ORDER_MAX || P.lpcSynth > VP_ORDER_MAX_SYNTH) return VP_ERR_ORDER;
+    struct Poison { vp_handle *h; bool armed; ~Poison() { if (armed) h->poisoned = true; } } guard{h, true};   // disarmed on success
+    int rc = sync_stream_state(h, st);
+    if (rc) return rc;
+    VpCall c0;
+    memset(&c0, 0, sizeof c0);
+    c0.inCounter = h->inCounter; c0.outCounter = h->outCounter; c0.currCounter = h->currCounter;
+    c0.inplace = inplace;
+    c0.iirFast = h->iirMode;
+    c0.nBlocks = 1;
+    // side-chain bus present or absent; the synth ring is written N samples per call, so after inSize samples of zeros
+    // (or straight after prepare) it holds nothing else and the mono path need not touch it
+    if (mono) {
+        c0.inMono = h->synthNonZero > 0 ? 1 : 2;
+        h->synthNonZero = std::max(0, h->synthNonZero - g.N * nBlocks);
     } else {
-        if (runVoc) {
-            VpCall cv = c;
-            cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
-            ProfScope ps(h, st, 1);
-            int nw = std::min(h->vocWaves, c.nWin);
-            if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
-            // large batches, FAST IIR: the register-light build with half the window slots, so that two workgroups share a
-            // CU (each slot then has two wavefronts; needs <= 80 KB of LDS per workgroup)
-            const int nl = voc_lite_slots(h, cv.iirFast != 0, nw);
-            const bool lite = nl > 0;
-            if (lite) nw = nl;
-            cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
-            cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
-            const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
-            hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : vp_k_vocoder, dim3(g.S), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, h->d, d_in, d_out);
+        c0.inMono = 0;
+        h->synthNonZero = g.inSize;
+    }
+    c0.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
+    c0.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
+
+    for (auto &co : h->cohorts) {
+        VpCall c = c0;
+        VpDev d = h->d;
+        d.streamMap = co.dMap;                                               // nullptr: workgroup b serves stream b
+        c.pitchOn = co.pitchOn; c.vocOn = co.vocOn;
+        // VocoderProcess::process (VocoderProcess.cpp:173-183): windows while startSample < N
+        c.vStart = co.vStart;
+        c.nWin = 0;
+        if (c.vocOn && co.vStart < g.N) c.nWin = (g.N - co.vStart + g.h - 1) / g.h;
+        // PitchProcess::process (PitchProcess.cpp:166-196): chunk steps while startSample < N
+        c.pStart = co.pStart; c.nChunk0 = co.nChunk;
+        c.nSteps = 0;
+        if (c.pitchOn && co.pStart < g.N) c.nSteps = (g.N - co.pStart + g.C - 1) / g.C;
+
+        // Kernel plan: ingest+gate runs as the prologue of the first DSP kernel and emit as the epilogue of
+        // the last one (all stages are one-workgroup-per-stream); they only stand alone when no DSP kernel runs.
+        // A launch that carries several blocks (pitch-only plan, process_blocks_device) runs the pitch kernel even when
+        // its FIRST block has no chunk step to do (N smaller than the chunk): later blocks of the launch do.
+        const bool runVoc = c.nWin > 0, runPitch = c.nSteps > 0 || (nBlocks > 1 && c.pitchOn);
+        if (!runVoc && !runPitch) {
+            { ProfScope ps(h, st, 0); hipLaunchKernelGGL(vp_k_ingest_gate, dim3(co.n), dim3(256), 0, st, g, c, d, d_in); }
+            { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, d, d_out); }
+        } else {
+            if (runVoc) {
+                VpCall cv = c;
+                cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
+                ProfScope ps(h, st, 1);
+                int nw = std::min(h->vocWaves, c.nWin);
+                if (nw < 4) nw = std::min(4, h->vocWaves);        // the fused ingest/emit want a few waves
+                // large batches, FAST IIR: the register-light build with half the window slots, so that two workgroups share a
+                // CU (each slot then has two wavefronts; needs <= 80 KB of LDS per workgroup)
+                const int nl = voc_lite_slots(h, cv.iirFast != 0, nw);
+                const bool lite = nl > 0;
+                if (lite) nw = nl;
+                cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
+                cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
+                const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
+                hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : vp_k_vocoder, dim3(co.n), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, d, d_in, d_out);
+            }
+            if (runPitch) {
+                VpCall cp = c;
+                cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
+                cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
+                ProfScope ps(h, st, 2);
+                const PitchPlan plan = pitch_plan(h, cp.iirFast != 0, cp.yinFft != 0, nBlocks);
+                cp.ldsBytes = (int)plan.lds;
+                hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
+            }
         }
-        if (runPitch) {
-            VpCall cp = c;
-            cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
-            cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
-            ProfScope ps(h, st, 2);
-            // large batches: the register-light build lets two workgroups share a CU (needs <= 80 KB LDS each and
-            // no big register-resident exact-IIR instantiation)
-            const bool lite = pitch_lite(h, cp.iirFast != 0, cp.yinFft != 0);
-            const size_t lds = lite ? h->pitchLds : h->pitchLds + (cp.yinFft ? vp_pitch_fft_lds_bytes(g) : 0);
-            auto k = lite ? (cp.iirFast ? vp_k_pitch_lite_fast : vp_k_pitch_lite) : (cp.iirFast ? vp_k_pitch_fast : vp_k_pitch);
-            if (!lite && pitch_common(h)) k = cp.iirFast ? vp_k_pitch_fast_c : vp_k_pitch_c;    // the common-case builds
-            if (lite && cp.iirFast && pitch_common(h)) k = vp_k_pitch_lite_fast_c;
-            if (nBlocks > 1) k = cp.iirFast ? (pitch_common(h) ? vp_k_pitch_fast_multi_c : vp_k_pitch_fast_multi) : vp_k_pitch_multi;   // never with `lite` or FFT (see the caller)
-            if (cp.yinFft) k = cp.iirFast ? vp_k_pitch_fast_fft : vp_k_pitch_fft;              // (never `lite`: pitch_lite())
-            cp.ldsBytes = (int)lds;
-            hipLaunchKernelGGL(k, dim3(g.S), dim3(512), lds, st, g, cp, h->d, d_in, d_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
+
+        // counters: VocoderProcess.cpp:176-182, PitchProcess.cpp:169-195 (once per block handled)
+        for (int b = 0; b < nBlocks; b++) {
+            if (co.vocOn) {
+                const int nWin = (co.vStart < g.N) ? (g.N - co.vStart + g.h - 1) / g.h : 0;
+                co.vStart = co.vStart + nWin * g.h - g.N;
+            }
+            if (co.pitchOn) {
+                const int nSteps = (co.pStart < g.N) ? (g.N - co.pStart + g.C - 1) / g.C : 0;
+                int nChunk = co.nChunk;
+                for (int i = 0; i < nSteps; i++) {
+                    if (nChunk % g.cpf == g.cpf - 1) nChunk = 1 % g.cpf;
+                    else nChunk += 1;
+                }
+                co.nChunk = nChunk;
+                co.pStart = co.pStart + nSteps * g.C - g.N;
+            }
         }
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
-
-    // counters: VocoderProcess.cpp:176-182, PitchProcess.cpp:169-195, MyBuffer.cpp:129-132 (once per block handled)
-    for (int b = 0; b < nBlocks; b++) {
-        if (c.vocOn) h->vStart = h->vStart + c.nWin * g.h - g.N;
-        if (c.pitchOn) {
-            const int nSteps = (h->pStart < g.N) ? (g.N - h->pStart + g.C - 1) / g.C : 0;
-            int nChunk = h->nChunk;
-            for (int i = 0; i < nSteps; i++) {
-                if (nChunk % g.cpf == g.cpf - 1) nChunk = 1 % g.cpf;
-                else nChunk += 1;
-            }
-            h->nChunk = nChunk;
-            h->pStart = h->pStart + nSteps * g.C - g.N;
-        }
+    for (int b = 0; b < nBlocks; b++) {                                      // MyBuffer.cpp:129-132
         h->outCounter = (h->outCounter + g.N) % g.outSize;
         h->inCounter = (h->inCounter + g.N) % g.inSize;
         h->currCounter = (h->currCounter + g.N) % g.inSize;
     }
+    guard.armed = false;
     return VP_OK;
 }
 
@@ -690,13 +777,16 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     if (!h || !d_in || !d_out || n_blocks < 1) return VP_ERR_INVALID_ARG;
     if (!h->prepared) return VP_ERR_NOT_PREPARED;
     if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
-    const vp_params &P = h->params;
+    if (h->poisoned) return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, 1, mono);       // reports it
+    int rc = sync_stream_state(h, (hipStream_t)hip_stream);                   // the plan below depends on the cohorts
+    if (rc) { h->poisoned = true; return rc; }
     const bool fast = h->iirMode == VP_IIR_FAST, fft = h->yinMode == VP_YIN_FFT && h->g.fftLog > 0;
-    if (P.pitchBool && !P.vocBool && n_blocks > 1 && !fft && !pitch_lite(h, fast, fft))   // one launch: state stays on chip between the blocks
+    const bool pitchOnly = h->cohorts.size() == 1 && h->cohorts[0].pitchOn && !h->cohorts[0].vocOn;
+    if (pitchOnly && n_blocks > 1 && !fft && !pitch_lite(h, fast, fft))      // one launch: state stays on chip between the blocks
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
     const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
     for (int b = 0; b < n_blocks; b++) {                       // other plans: block by block
-        int rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0, 1, mono);
+        rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0, 1, mono);
         if (rc) return rc;
     }
     return VP_OK;
@@ -931,10 +1021,18 @@ extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int fram
     if (!out || n_streams <= 0 || frame_len < 8 || hop <= 0 || n_samples < frame_len) return VP_ERR_INVALID_ARG;
     int lg = 0;
     while ((1 << lg) < frame_len) lg++;
-    if ((1 << lg) != frame_len || lg > 12 || frame_len % hop) return VP_ERR_GEOMETRY;
+    // (hop == frame_len: the sqrt-Hann windows do not overlap and w[0]^2 = 0 cannot be normalised; at least two frames must cover every sample)
+    if ((1 << lg) != frame_len || lg > 12 || frame_len % hop || frame_len / hop < 2) return VP_ERR_GEOMETRY;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    {   // 4096-point frames need 96 KB of dynamic LDS: above the default ceiling of the function
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void *)vp_k_stft_frames) != hipSuccess ||
+            hipFuncSetAttribute((const void *)vp_k_stft_frames, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(160 * 1024 - fa.sharedSizeBytes)) != hipSuccess)
+            return VP_ERR_HIP;
+    }
     vp_stft *p = new vp_stft();
     p->device = device; p->logF = lg; p->F = frame_len; p->hop = hop; p->S = n_streams; p->T = n_samples;
     p->nFrames = (n_samples - frame_len) / hop + 1;

@@ -94,13 +94,25 @@ struct VpDev {
     const double *twRe, *twIm; // [M/2] exp(-2 pi i j / M)
     unsigned long long *ub;  // [5]
     unsigned long long *dbg; // [64] phase timers of the -DVP_STAMPS diagnostic build
+    const int *streamMap;    // launch of a cohort (streams whose pitchBool/vocBool histories differ from the others'):
+                             // workgroup b serves stream streamMap[b]; nullptr (the normal case): stream b
 };
 
-// doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
-#if defined(__HIPCC__) || defined(__CUDACC__)
-__host__ __device__
+#if defined(__HIPCC__)
+#define VP_HD __host__ __device__
+#else
+#define VP_HD
 #endif
-static inline size_t voc_wave_doubles(int W)
+
+// Pitch kernel, LDS: length (doubles) of the yinTemp and running-sum regions.  They double as scratch once the pitch is
+// picked -- the PSOLA grain table (2 x VP_MARKS doubles + 5 x VP_MARKS ints from dY[0]), the exact recursion's history
+// (cum[0 .. order)), the block-form IIR's impulse response and input (cum[128 .. 320)) -- so at low sample rates, where
+// tauMax + 1 is smaller than that scratch, the regions are sized for the scratch instead.
+VP_HD static inline int vp_dy_len(int tauMax) { const int need = 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2; return tauMax + 1 > need ? tauMax + 1 : need; }
+VP_HD static inline int vp_cum_len(int tauMax) { return tauMax + 1 > 320 ? tauMax + 1 : 320; }
+
+// doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
+VP_HD static inline size_t voc_wave_doubles(int W)
 {
     return (size_t)4 * W + 2 * (VP_ORDER_MAX + 1) + 2 * (VP_ORDER_MAX_SYNTH + 1) + 2;    // A B Cc D | rV aV | rS aS | pad (even: 16-byte alignment)
 }

@@ -24,7 +24,7 @@ __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
 // bytes of dynamic LDS vp_k_pitch needs for a geometry
 static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
 {
-    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + 2 * (size_t)(g.tauMax + 1) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (2 * (size_t)g.tauMax + 2);
+    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (2 * (size_t)g.tauMax + 2);
     return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
 }
 // extra dynamic LDS of the VP_YIN_FFT accelerator (re/im arrays)

@@ -95,6 +95,12 @@ __device__ __forceinline__ int vp_tid()
     return t;
 }
 
+// the stream this workgroup serves (see VpDev::streamMap)
+__device__ __forceinline__ int vp_stream(const VpDev &d)
+{
+    return d.streamMap ? d.streamMap[blockIdx.x] : (int)blockIdx.x;
+}
+
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
                                            const lds_state *stl = nullptr, int boff = 0);
@@ -136,7 +142,7 @@ __device__ __forceinline__ double wave_sum(double v)
 __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in,
                                                   int boff = 0)
 {
-    const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int s = vp_stream(d), tid = threadIdx.x, nt = blockDim.x;
     float *vr = d.voiceRing + (size_t)s * g.inSize;
     float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     float *sr1 = sr0 + g.inSize;
@@ -763,7 +769,7 @@ __device__ __forceinline__ void iir_block_wave_regs(const lds_f64 *x, lds_f64 *y
 template <bool LITE>
 __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, const VpDev &d, double *smem)
 {
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = vp_stream(d), tid = threadIdx.x;
     const int waveHw = tid >> 6, lane = tid & 63, nWaves = c.vocWin;      // nWaves: windows per round
     // The launch carries nRoles wavefronts per window slot: wavefront waveHw works for window waveHw % vocWin in role
     // waveHw / vocWin.  Role 0 owns the window (everything ordered or serial); the others share its storage and take
@@ -1131,43 +1137,43 @@ __device__ __forceinline__ void pitch_marks(const VpGeom &g, const PitchLds &L, 
                             front = _v; if (n < VP_MARKS) n++; } while (0)
 
     if (pitch > 1) {
-        const int sw_c = (int)floor(g.delta * period);
-        const int sw_f = (int)ceil((2.0 - g.delta) * period);
-        bool searchLeft = false;
+        const int gapMin = (int)floor(g.delta * period);
+        const int gapMax = (int)ceil((2.0 - g.delta) * period);
+        bool growLeft = false;
         int t;
         if (prevPitch > 1) {
             if (nOv == 0) {
-                int lastMark = marks_back(st->prevAnMarks, nPrev, ub);
-                int l_lim = max(lastMark + min(sw_c, (int)floor(g.delta * min(prevPeriod, period))), 0);
-                int r_lim = min(lastMark + max(sw_f, (int)ceil((2 - g.delta) * max(prevPeriod, period))), g.F);
-                t = wave_arg_min(L, g.toKeep, l_lim, r_lim);
+                int tailMark = marks_back(st->prevAnMarks, nPrev, ub);
+                int winLo = max(tailMark + min(gapMin, (int)floor(g.delta * min(prevPeriod, period))), 0);
+                int winHi = min(tailMark + max(gapMax, (int)ceil((2 - g.delta) * max(prevPeriod, period))), g.F);
+                t = wave_arg_min(L, g.toKeep, winLo, winHi);
             } else
                 t = st->prevAnMarks[nPrev - nOv];
         } else {
-            searchLeft = true;
+            growLeft = true;
             t = wave_arg_min(L, g.toKeep, 0, g.F);
         }
         PUSH_BACK(t);
-        while (back + sw_c < g.F) {                                         // :505-519
-            if (back + sw_f < g.F) {
-                int m = wave_arg_min(L, g.toKeep, back + sw_c, back + sw_f);
+        while (back + gapMin < g.F) {                                         // :505-519
+            if (back + gapMax < g.F) {
+                int m = wave_arg_min(L, g.toKeep, back + gapMin, back + gapMax);
                 PUSH_BACK(m);
             } else {
                 if (back + period < g.F) {
-                    int m = wave_arg_min(L, g.toKeep, back + sw_c, g.F);
+                    int m = wave_arg_min(L, g.toKeep, back + gapMin, g.F);
                     PUSH_BACK(m);
                 }
                 break;
             }
         }
-        if (searchLeft) {                                                    // :522-539
-            while (front - sw_c > 0) {
-                if (front - sw_f >= 0) {
-                    int m = wave_arg_min(L, g.toKeep, front - sw_f, front - sw_c);
+        if (growLeft) {                                                    // :522-539
+            while (front - gapMin > 0) {
+                if (front - gapMax >= 0) {
+                    int m = wave_arg_min(L, g.toKeep, front - gapMax, front - gapMin);
                     PUSH_FRONT(m);
                 } else {
                     if (front - period >= 0) {
-                        int m = wave_arg_min(L, g.toKeep, 0, front - sw_c);
+                        int m = wave_arg_min(L, g.toKeep, 0, front - gapMin);
                         PUSH_FRONT(m);
                     }
                     break;
@@ -1234,30 +1240,30 @@ __device__ __forceinline__ void place_st_marks(const VpGeom &g, const VpCall &c,
     if (st->periodNew <= 0) return;                 // the reference asserts (:604-608)
     const int nPrev = st->nPrevSt;
     const int periodNew = st->periodNew;
-    int firstMark;
+    int headMark;
     if (st->pitch > 1) {
         if (st->prevPitch > 1) {
             if (nOv > 0)
-                firstMark = st->prevStMarks[nPrev - nOv];
+                headMark = st->prevStMarks[nPrev - nOv];
             else {
                 int b = marks_back(st->prevStMarks, nPrev, ub);
-                firstMark = (b + periodNew >= 0) ? b + periodNew : st->anMarks[0];
+                headMark = (b + periodNew >= 0) ? b + periodNew : st->anMarks[0];
             }
         } else
-            firstMark = st->anMarks[0];
+            headMark = st->anMarks[0];
     } else {
         if (nPrev == 0) return;
         if (nOv > 0)
-            firstMark = st->prevStMarks[nPrev - nOv];
+            headMark = st->prevStMarks[nPrev - nOv];
         else {
             int b = st->prevStMarks[nPrev - 1];
             int n = 1;
             while (b + n * periodNew < 0) n += 1;
-            firstMark = b + n * periodNew;
+            headMark = b + n * periodNew;
         }
     }
     int n = 0;
-    st->stMarks[n++] = firstMark;
+    st->stMarks[n++] = headMark;
     while (st->stMarks[n - 1] + periodNew < g.F) {
         int v = st->stMarks[n - 1] + periodNew;
         if (n < VP_MARKS) st->stMarks[n] = v;
@@ -2213,7 +2219,7 @@ template <bool LITE, bool FAST, bool MULTI, bool FFT, bool COMMON>
 __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in0,
                                                   float *__restrict__ out0, double *smem)
 {
-    const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int s = vp_stream(d), tid = threadIdx.x, nt = blockDim.x;
 #ifdef VP_STAMPS
     const unsigned long long wgT0 = wall_clock64();
 #endif
@@ -2234,8 +2240,8 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
     L.oE = L.eF + g.eLen;
     L.yF = L.oE + g.F;
     L.dY = L.yF + g.F;
-    L.cum = L.dY + (g.tauMax + 1);
-    L.r = L.cum + (g.tauMax + 1);
+    L.cum = L.dY + vp_dy_len(g.tauMax);               // (both sized for what later phases park there, vp_common.h)
+    L.r = L.cum + vp_cum_len(g.tauMax);
     L.aPrev = L.r + (VP_ORDER_MAX + 1);
     L.qtab = L.aPrev + (VP_ORDER_MAX + 1);            // [2 tauMax + 2] PSOLA quotient table (also Levinson scratch)
     L.qtab += (int)((L.qtab - (lds_f64 *)smem) & 1);  // keep it 16-byte aligned
@@ -2516,7 +2522,7 @@ __global__ __launch_bounds__(512, 4) void vp_k_pitch_lite_fast(VpGeom g, VpCall 
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
                                            const lds_state *stl, int boff)
 {
-    const int s = blockIdx.x;
+    const int s = vp_stream(d);
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
     const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     const float *sr1 = sr0 + g.inSize;

@@ -27,42 +27,54 @@ def shard_sizes(n_streams, world):
 def scatter_streams(x_root, n_streams, tail_shape, dtype, device, src=0, group=None):
     """Rank `src` holds x_root [n_streams, *tail_shape]; every rank returns its own shard.
 
-    Point-to-point isend/irecv (no padding needed for ragged shards)."""
+    Point-to-point (no padding needed for ragged shards), issued as ONE batch_isend_irecv group: under RCCL every
+    peer pair otherwise sets its channel up lazily, one after the other.  `src` is a rank OF THE GROUP."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_streams, rank, world)
     mine = torch.empty((hi - lo, *tail_shape), dtype=dtype, device=device)
+    ops = []
     if rank == src:
-        reqs = []
         for r in range(world):
             rlo, rhi = shard_range(n_streams, r, world)
             if r == src:
                 mine.copy_(x_root[rlo:rhi])
             elif rhi > rlo:
-                reqs.append(dist.isend(x_root[rlo:rhi].contiguous(), dst=r, group=group))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.isend, x_root[rlo:rhi].contiguous(), _global_rank(group, r), group))
     elif hi > lo:
-        dist.recv(mine, src=src, group=group)
+        ops.append(dist.P2POp(dist.irecv, mine, _global_rank(group, src), group))
+    _run(ops)
     return mine
 
 
-def gather_streams(y_local, n_streams, dst=0, group=None):
-    """Inverse of scatter_streams: rank `dst` returns [n_streams, *tail], the others None."""
+def _global_rank(group, r):
+    """isend/irecv/P2POp take GLOBAL ranks; shard ownership is by rank within the group."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def _run(ops):
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+
+
+def gather_streams(y_local, n_streams, dst=0, group=None, out=None):
+    """Inverse of scatter_streams: rank `dst` (of the group) returns [n_streams, *tail], the others None.
+    `out` (optional, on `dst`): a preallocated [n_streams, *tail] tensor to receive into."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     tail = tuple(y_local.shape[1:])
     if rank == dst:
-        out = torch.empty((n_streams, *tail), dtype=y_local.dtype, device=y_local.device)
-        reqs = []
+        if out is None:
+            out = torch.empty((n_streams, *tail), dtype=y_local.dtype, device=y_local.device)
+        ops = []
         for r in range(world):
             rlo, rhi = shard_range(n_streams, r, world)
             if r == dst:
                 out[rlo:rhi].copy_(y_local)
             elif rhi > rlo:
-                reqs.append((dist.irecv(out[rlo:rhi], src=r, group=group)))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], _global_rank(group, r), group))
+        _run(ops)
         return out
     lo, hi = shard_range(n_streams, rank, world)
     if hi > lo:
-        dist.send(y_local.contiguous(), dst=dst, group=group)
+        _run([dist.P2POp(dist.isend, y_local.contiguous(), _global_rank(group, dst), group)])
     return None
