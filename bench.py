@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the pitch-corrector / vocoder hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode pitch|voc|both] [--streams S] [--block N]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode pitch|voc|both] [--streams S] [--block N] [--exchange]
 
-A "step" is one processBlock() over the whole stream batch: S streams x N samples (default the
+A "step" is one processBlock() over the whole stream batch: S streams x N samples per GPU (default the
 BASELINE.json configs[1] workload: 256 mono streams, pitch corrector only, 1024-sample frames,
 256-sample hop, 44.1 kHz, host block N = 1024).  The metric unit "frame" is one 256-sample hop of
-one stream through the enabled path, so a step is S*N/256 frames.
+one stream through the enabled path, so a step is S*N/256 frames per GPU.
 
 Inputs are synthetic (vocoderproject_amd.synth) and already resident in HBM when the timed region
-starts.  One process per GPU; for N > 1 every rank owns its own S streams (weak scaling, streams
-are independent: no data-path collective), rank 0 prints ONE JSON line.
+starts.  One process per GPU.  `--gpus N` with N > 1 and no launcher (WORLD_SIZE unset) makes this
+process spawn N rank processes itself (before anything here touches a GPU) and wait for them; under
+`python -m torch.distributed.run ...` the ranks are the launcher's.  Every rank owns its own S streams
+(weak scaling, streams are independent: no data-path collective in `value`), rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
   roofline     -- dominant kernel, ALGORITHMIC bytes (3072 B per pitch frame, 5120 B with the
                   vocoder) / its HIP-event duration vs the 8 TB/s HBM peak (the path is
-                  ALU/latency-bound, the fraction is tiny by construction)
+                  ALU/latency-bound, the fraction is tiny by construction); `traffic` and
+                  `valu` come from the committed rocprofv3 PMC passes of THIS kernel build (matched by kernel
+                  name and by a hash of the kernel sources, null when either differs)
   cpu_baseline -- the CPU oracle (the build's restatement of the reference, kind "port") timed on
-                  this host's cores on a bounded sample of the same workload.
+                  this host's cores on a bounded sample of the same workload (rank 0, one GPU only)
+  rccl         -- (N > 1, or --exchange) what torch.distributed backend "nccl" (= RCCL) saw: world size, the
+                  all-reduced sum of ranks
+  exchange     -- SURVEY 8(e)'s root fan-out/fan-in: rank 0 holds the whole batch, per step scatter_streams ->
+                  processBlock -> gather_streams, double-buffered; frames/s beside the resident-input `value`
+  configs3     -- the same hot path at BASELINE configs[3]'s per-GPU share (1024 streams, pitch + vocoder)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,12 +45,11 @@ FS = 44100.0
 HOP = 256
 ALG_BYTES_PER_FRAME = {"pitch": 3072, "voc": 5120, "both": 5120}
 PROFILE_EVERY = 8       # kernel durations are sampled live inside the timed region (two event records cost the stream 2-3 us)
-# fp64 operations per hop-frame of the reference's arithmetic at the default geometry:
-# the secondary, ALU-side sanity line (no MFMA: nothing on this path is a dense contraction)
-ALG_FLOP_PER_FRAME = {"pitch": 0.51e6, "voc": 0.36e6, "both": 0.87e6}
-FP64_VALU_PEAK_TFLOPS = 78.6                                            # vector fp64 peak used by SURVEY.md section 8d (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+# fp64 vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (an FMA counts once here: these are lane-operations)
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md
 UNIQUE_BLOCKS = 16                                                      # synthetic input ring, cycled
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
 def usable_cores():
@@ -52,6 +63,29 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def kernel_source_hash():
+    """sha256 over what the kernels are built from: a counter file measured on other sources is not this build's."""
+    h = hashlib.sha256()
+    for rel in ("vocoderproject_amd/csrc/vp_kernels.hip", "vocoderproject_amd/csrc/vp_common.h", "vocoderproject_amd/csrc/vp_kernels.h",
+                "vocoderproject_amd/build.py"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kernel, workload_key):
+    """Per-launch PMC figures of `kernel` at `workload_key` from profiles/r02_counters.json (tools/collect_counters.sh:
+    separate rocprofv3 --pmc passes of this very command); None unless kernel build name AND source hash match."""
+    try:
+        with open(COUNTERS_JSON) as f:
+            t = json.load(f)
+        if t.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        return t["kernels"].get(f"{kernel}@{workload_key}")
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(mode, N, seconds_target=12.0):
@@ -91,19 +125,6 @@ def cpu_baseline(mode, N, seconds_target=12.0):
                       f"{dt:.1f} s wall"}
 
 
-def measured_traffic(mode, S, N, iir, mono=False):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this very command); None when the
-    configuration being benched is not the one that was profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)
-        key = f"{mode}{'-mono' if mono else ''}/S{S}/N{N}/{iir}"
-        return t["per_launch_bytes"].get(key)
-    except (OSError, ValueError, KeyError):
-        return None
-
-
 def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
     """Standalone STFT->iSTFT kernel (Hann, radix-2 FFT, iFFT, OLA): NO reference counterpart, reported apart
     from the metric."""
@@ -125,6 +146,36 @@ def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
             "hbm_gbs": (2 * S * T * 4 + 2 * frames * F * 4) / dt / 1e9}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N rank processes, one per GPU, started from a parent that has not
+    initialised the GPU (torch.cuda.device_count() does not).  Rank 0's stdout is this process's stdout."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py --gpus {n}: this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 3600
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:                       # our own children only, by pid
+        if p.poll() is None:
+            p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,12 +188,12 @@ def main():
                     help="arithmetic of the two synthesis IIRs: 'fast' (VP_IIR_FAST, tolerance-tested) is the measured "
                          "configuration; 'exact' (bit-identical to the oracle) is timed beside it as value_exact_mode")
     ap.add_argument("--single-mode", action="store_true",
-                    help="do not time the other IIR mode or the STFT kernel (for profiler runs: one kernel population)")
+                    help="do not time the other IIR mode, the STFT kernel or the secondary configurations (for profiler runs: one kernel population)")
     ap.add_argument("--yin", default="xcorr", choices=["direct", "xcorr", "fft"],
                     help="evaluation of the YIN difference function: 'xcorr' (default) is certified to take the same "
                          "decisions as 'direct' (the reference's arithmetic) and falls back to it otherwise: same output bits")
     ap.add_argument("--blocks-per-step", type=int, default=1,
-                    help="host blocks of N samples handed over per step (vp_process_blocks_device; one launch in pitch mode)")
+                    help="host blocks of N samples handed over per step (vp_process_blocks_device)")
     ap.add_argument("--shift", type=float, default=None,
                     help="extension (no reference counterpart): fixed pitch-shift interval in semitones, +x on even and -x "
                          "on odd streams (vp_set_pitch_shift), instead of the correction to the key's nearest note")
@@ -152,13 +203,21 @@ def main():
     ap.add_argument("--cfg5", action="store_true",
                     help="BASELINE configs[4] geometry instead of the default one: 48 kHz, 2048-point frames hop 512 (pitch "
                          "2048/1536, vocoder 2048/512), LPC orders 48/48/30, host block 2048 (a documentation figure: use with --mode both --no-cpu)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="also time SURVEY 8(e)'s exchange: rank 0 holds the whole batch; per step scatter -> processBlock -> gather "
+                         "(double-buffered, RCCL point-to-point).  On by default when N > 1.")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    # (VP_BENCH_SPAWN=1: take the spawning route even for one rank -- how the route is tested on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("VP_BENCH_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # nothing above touched a GPU
+
     import torch
     import torch.distributed as dist
     from vocoderproject_amd import BatchVocoderProcessor
+    from vocoderproject_amd.dist import gather_streams, scatter_streams
     from vocoderproject_amd.synth import make_streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,26 +225,40 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("VP_BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    do_exchange = (args.exchange or world > 1) and not args.single_mode and args.blocks_per_step == 1
+    use_dist = world > 1 or do_exchange or os.environ.get("VP_BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    rccl = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        rs = torch.tensor([float(rank)], dtype=torch.float64, device=dev)
+        dist.all_reduce(rs, op=dist.ReduceOp.SUM)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_sum": float(rs.item()),
+                "rank_sum_expected": world * (world - 1) / 2.0}
     n_gpus = world
 
     S, N, mode = args.streams, args.block, args.mode
     global FS, HOP
     if args.cfg5:
         FS, HOP, N = 48000.0, 512, 2048
-        p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"),
-                                  lpcVoice=48, lpcPitch=48, lpcSynth=30)
-        p.prepareExplicit(FS, N, S, 2048, 1536, 2048, 512)
-    else:
-        p = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode != "voc"), vocBool=int(mode != "pitch"))
-        p.prepareToPlay(FS, N, S)
-    p.set_yin_mode(args.yin)
+
+    def make_processor(mode_, S_):
+        if args.cfg5:
+            q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"),
+                                      lpcVoice=48, lpcPitch=48, lpcSynth=30)
+            q.prepareExplicit(FS, N, S_, 2048, 1536, 2048, 512)
+        else:
+            q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"))
+            q.prepareToPlay(FS, N, S_)
+        q.set_yin_mode(args.yin)
+        return q
+
+    p = make_processor(mode, S)
 
     def set_shift(semi):
         for s_ in range(S):
@@ -221,6 +294,29 @@ def main():
             else:
                 p.process_blocks_device(x[b0:b0 + BPS], y, stream.cuda_stream)
 
+    def region(fn, steps, warmup):
+        """W untimed calls of fn, then exactly K timed ones between barrier + synchronize on both sides"""
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    def max_over_ranks(*vals):
+        t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
     def timed(mode_iir, steps, warmup):
         p.set_iir_mode(mode_iir)
         for i in range(warmup):
@@ -228,17 +324,7 @@ def main():
         torch.cuda.synchronize(dev)
         p.profile_read(reset=True)
         p.profile_enable(PROFILE_EVERY)       # HIP events around every PROFILE_EVERY-th launch of the timed region
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        dt_ = time.perf_counter() - t0
+        dt_ = region(lambda i: step(warmup + i), steps, 0)
         p.profile_enable(False)
         return dt_, p.profile_read(reset=True)
 
@@ -255,44 +341,103 @@ def main():
     if not args.single_mode and BPS == 1 and mode == "pitch" and U % MB == 0:
         ymb = torch.empty((MB, S, 2, N), dtype=torch.float32, device=dev)
         p.set_iir_mode(args.iir)
-        def step_mb(b0):
+
+        def step_mb(i):
+            b0 = (i * MB) % U
             if mono:
                 p.process_blocks_mono_device(xm[b0:b0 + MB], ymb, stream.cuda_stream)
             else:
                 p.process_blocks_device(x[b0:b0 + MB], ymb, stream.cuda_stream)
 
-        for i in range(2):
-            step_mb(0)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(k3):
-            step_mb((i * MB) % U)
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        dt_mb = time.perf_counter() - t0
+        dt_mb = region(step_mb, k3, 2)
     dt, prof = timed(args.iir, args.steps, args.warmup)
 
-    tt = torch.tensor([dt, dt_other, dt_mb], dtype=torch.float64, device=dev)
     chk = y.double().abs().sum().view(1)
     if use_dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(chk, op=dist.ReduceOp.SUM)          # the only collective: a checksum of the outputs
-    dt, dt_other, dt_mb = float(tt[0].item()), float(tt[1].item()), float(tt[2].item())
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)          # a checksum of the outputs (not on the data path)
+    dt, dt_other, dt_mb = max_over_ranks(dt, dt_other, dt_mb)
+
     # a third secondary figure, AFTER the headline region: BASELINE configs[1]'s "+-12-semitone pitch shift" (fixed
     # interval, +12 on even and -12 on odd streams; extension without a reference counterpart, parity GPU <-> oracle)
     dt_shift = float("nan")
     if not args.single_mode and args.shift is None and mode != "voc" and BPS == 1:
         set_shift(12.0)
         dt_shift, _ = timed(args.iir, k2, max(4, args.warmup // 2))
-        ts = torch.tensor([dt_shift], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        dt_shift = float(ts[0].item())
+        (dt_shift,) = max_over_ranks(dt_shift)
+        for s_ in range(S):
+            p.setPitchShift(0.0, on=False, stream=s_)
 
     frames_per_step_gpu = S * N * BPS // HOP
+
+    # the batch lives on rank 0; per step root fan-out (scatter_streams), processBlock on every rank, root
+    # fan-in (gather_streams).  Double-buffered: step i+1's scatter and step i-1's gather ride RCCL's stream beside step
+    # i's kernels.  Same handle, same streams as the resident-input region above.
+    exch = None
+    if do_exchange:
+        C_in = 1 if mono else 3
+        tail_in = (N,) if mono else (3, N)
+        Sg = S * world
+        if rank == 0:
+            xr = make_streams(Sg, N * U, fs=FS, first_stream=0, device=dev).view(Sg, 3, U, N).permute(2, 0, 1, 3)
+            xr = (xr[:, :, 0, :] if mono else xr).contiguous()                     # [U][Sg][N] or [U][Sg][3][N]
+            yr = [torch.empty((Sg, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
+        inb = [torch.empty((S, *tail_in), dtype=torch.float32, device=dev) for _ in range(2)]
+        outb = [torch.empty((S, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
+        p.set_iir_mode(args.iir)
+
+        def wait(ws):
+            for w in ws or []:
+                w.wait()
+
+        def run_exchange(steps):
+            wsc, wga = [None, None], [None, None]
+            _, wsc[0] = scatter_streams(xr[0] if rank == 0 else None, Sg, tail_in, torch.float32, dev, out=inb[0], async_op=True)
+            for i in range(steps):
+                cur = i & 1
+                wait(wsc[cur])
+                if i + 1 < steps:
+                    _, wsc[1 - cur] = scatter_streams(xr[(i + 1) % U] if rank == 0 else None, Sg, tail_in, torch.float32, dev,
+                                                      out=inb[1 - cur], async_op=True)
+                wait(wga[cur])                            # step i-2's gather has read outb[cur]
+                if mono:
+                    p.process_mono_device(inb[cur], outb[cur], stream.cuda_stream)
+                else:
+                    p.process_device(inb[cur], outb[cur], stream.cuda_stream)
+                _, wga[cur] = gather_streams(outb[cur], Sg, out=yr[cur] if rank == 0 else None, async_op=True)
+            wait(wga[0]); wait(wga[1])
+
+        ke = max(16, args.steps // 2)
+        run_exchange(4)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run_exchange(ke)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        (dte,) = max_over_ranks(time.perf_counter() - t0)
+        exch = {"value": frames_per_step_gpu * ke * n_gpus / dte, "unit": "frames/s", "ms_per_step": dte / ke * 1e3, "steps": ke,
+                "bytes_scattered_per_step": (Sg - S) * C_in * N * 4, "bytes_gathered_per_step": (Sg - S) * 2 * N * 4,
+                "what": "rank 0 holds the batch: scatter_streams -> processBlock -> gather_streams per step, double-buffered, "
+                        "RCCL point-to-point (batch_isend_irecv); root's own shard is a local copy"}
+
+    # BASELINE configs[3]'s per-GPU share (8192 streams over 8 GPUs = 1024 per GPU, pitch corrector + vocoder), same geometry
+    cfg3 = None
+    if not args.single_mode and not args.cfg5 and BPS == 1 and not (mode == "both" and S == 1024):
+        S3 = 1024
+        p3 = make_processor("both", S3)
+        p3.set_iir_mode(args.iir)
+        x3 = make_streams(S3, N * 4, fs=FS, first_stream=rank * S3, device=dev).view(S3, 3, 4, N).permute(2, 0, 1, 3).contiguous()
+        y3 = torch.empty((S3, 2, N), dtype=torch.float32, device=dev)
+        k4 = max(8, args.steps // 8)
+        dt3 = region(lambda i: p3.process_device(x3[i % 4], y3, stream.cuda_stream), k4, 3)
+        (dt3,) = max_over_ranks(dt3)
+        cfg3 = {"value": (S3 * N // HOP) * k4 * n_gpus / dt3, "unit": "frames/s", "ms_per_step": dt3 / k4 * 1e3, "steps": k4,
+                "streams_per_gpu": S3, "mode": "both", "iir_mode": args.iir,
+                "kernel_builds": {"pitch": p3.pitch_kernel_name(), "vocoder": p3.vocoder_kernel_name()}}
+        del p3, x3, y3
+
     total_frames = frames_per_step_gpu * args.steps * n_gpus
     value = total_frames / dt
 
@@ -302,8 +447,22 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else dom
         ms, n = prof[dom]
         avg_s = (ms / max(n, 1)) * 1e-3
+        dom_build = p.vocoder_kernel_name() if dom == "vp_k_vocoder" else p.pitch_kernel_name() if dom == "vp_k_pitch" else dom
         alg_bytes = ALG_BYTES_PER_FRAME[mode] * (HOP // 256) * frames_per_step_gpu      # f32 I/O per hop-frame (hop 512: twice the samples)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        wkey = f"{'cfg5' if args.cfg5 else 'cfg'}/{mode}{'-mono' if mono else ''}/S{S}/N{N}/{args.iir}/{args.yin}"
+        ctr = committed_counters(dom_build, wkey) if BPS == 1 else None
+        roof = {"bound": "hbm", "kernel": dom_build, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": ctr["hbm_bytes_per_launch"] if ctr else None,
+                "avg_kernel_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
+                "note": "path is fp64-VALU/latency-bound (DESIGN.md); HBM fraction is reported as the contract asks"}
+        if ctr:
+            # what the kernel EXECUTED (rocprofv3 --pmc SQ_INSTS_VALU of this build, per launch), against the fp64 vector issue peak
+            lane_ops = ctr["SQ_INSTS_VALU"] * 64.0
+            roof["valu"] = {"insts_per_launch": ctr["SQ_INSTS_VALU"], "lane_ops_per_s": lane_ops / avg_s, "peak_lane_ops_per_s": VALU_LANE_OPS_PEAK,
+                            "frac": lane_ops / avg_s / VALU_LANE_OPS_PEAK, "valu_busy_frac_of_wave_cycles": ctr.get("valu_active_over_wave_cycles"),
+                            "what": "executed vector instructions x 64 lanes per second vs 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz "
+                                    "(upper bound on useful work: serial phases run all 64 lanes redundantly)"}
         out = {
             "metric": "STFT-geometry frames/sec (1024-pt frames, hop 256) through the pitch-corrector/vocoder path",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -314,27 +473,28 @@ def main():
                                    f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
                        "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "input": "mono voice [S][N]" if mono else "[S][3][N]", "frames_per_step": frames_per_step_gpu * n_gpus,
                        "kernel_builds": {"pitch": p.pitch_kernel_name() if mode != "voc" else None, "vocoder": p.vocoder_kernel_name() if mode != "pitch" else None},
-                       "parallelism": f"streams sharded over {n_gpus} GPU(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_kernel_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
-                         "note": "path is fp64-VALU/latency-bound (DESIGN.md); HBM fraction is reported as the contract asks",
-                         "alu_sanity": {"achieved": ALG_FLOP_PER_FRAME[mode] * value / n_gpus / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": ALG_FLOP_PER_FRAME[mode] * value / n_gpus / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                        "what": "reference-arithmetic fp64 ops per hop-frame x frames/s per GPU, default orders"}},
+                       "kernel_source_hash": kernel_source_hash(),
+                       "parallelism": f"streams sharded over {n_gpus} GPU(s), one process per GPU, no data-path collective"},
+            "roofline": roof,
             "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if v[1]},
             "checksum": float(chk.item()),
             f"value_{other}_mode": (frames_per_step_gpu * k2 * n_gpus / dt_other) if dt_other == dt_other else None,
             "value_8_blocks_per_call": ((S * N * MB // HOP) * k3 * n_gpus / dt_mb) if dt_mb == dt_mb else None,
             "value_pm12_semitone_shift": (frames_per_step_gpu * k2 * n_gpus / dt_shift) if dt_shift == dt_shift else None,
         }
+        if rccl:
+            out["rccl"] = rccl
+        if exch:
+            out["exchange"] = exch
+        if cfg3:
+            out["configs3"] = cfg3
         if not args.single_mode:
             out["stft_kernel"] = stft_figure(dev, S)
-        out["roofline"]["traffic"] = measured_traffic(mode, S, N, args.iir, mono) if BPS == 1 else None
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -199,8 +199,9 @@ const char *vp_vocoder_kernel_name(const vp_handle *h);
  * same meaning as the oracle's counters. Synchronises. */
 int vp_read_ub_counters(vp_handle *h, long out[5]);
 
-/* Slots 0..61: diagnostic build (-DVP_STAMPS) only, per-phase timers (100 MHz ticks) of workgroup 0, all zero in
- * the product build.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
+/* Slots 0..58: diagnostic build (-DVP_STAMPS) only, per-phase timers (100 MHz ticks) of workgroup 0, all zero in
+ * the product build.  Slots 59 / 60 / 61 (every build): wavefronts whose bounded wait for an in-workgroup flag (YIN prefix
+ * sums / LPC coefficients / grain table) ran out -- always 0; anything else is a bug.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
  * certified / handed to the reference's arithmetic. */
 int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
 /* Diagnostic build only: ticks each of the first n streams' workgroups spent inside the pitch kernel (which stream paces a launch). */

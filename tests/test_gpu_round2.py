@@ -298,3 +298,42 @@ def test_scatter_gather_over_nccl_world_size_1():
         o.prepare_to_play(FS, N)
         ref.append(o.run(x[s_]))
     _assert_equal(got, np.stack(ref), "nccl world 1")
+
+
+# ---- large batches from a cold start, certified-YIN fallback path -------------------------------------------------------
+
+@pytest.mark.parametrize("yin", ["xcorr", "xcorr_force_fallback"])
+@pytest.mark.parametrize("mode", ["pitch", "both"])
+def test_large_batch_cold_start_fallback_frames(yin, mode):
+    """Round-2 finding: at 1024 streams (two workgroups per CU, second-round workgroups starting beside a running one)
+    the first block -- whose all-zero first frame sends every stream through the certified YIN's fallback -- came out
+    wrong (NaN) for a few streams and some in-kernel flag waits ran into their bound: a wavefront could read the
+    certification verdict after it had been reset and leave the others one barrier out of step.  Every copy of a stream
+    must come out identical wherever it sits in the batch, no flag wait may time out, and sampled streams must match
+    the oracle (decisions exactly; samples within the FAST tolerance)."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, B, U = 1024, 1024, 4, 16
+    base = _streams(U, N * B)
+    x = np.ascontiguousarray(base[np.arange(S) % U])
+    params = dict(vocBool=int(mode == "both"))
+    for rep in range(3):                                              # the fault was intermittent
+        p = BatchVocoderProcessor(**params)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode("fast")
+        p.set_yin_mode(yin)
+        assert p.pitch_kernel_name() == "vp_k_pitch_lite_fast_c"
+        p.debug_stamps(reset=True)
+        got = p.run(x)
+        st = p.debug_stamps(reset=False)
+        assert st[59] == 0 and st[60] == 0 and st[61] == 0, ("flag waits timed out", st[59:62])
+        assert np.isfinite(got).all()
+        for u in range(U):
+            assert np.all(got[u::U] == got[u]), (rep, u)
+    ref = []
+    for u in range(U):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(FS, N)
+        ref.append(o.run(base[u]))
+    err = got[:U].astype(np.float64) - np.stack(ref)
+    assert np.sqrt((err ** 2).mean()) < 1e-4

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Runs on the GPU box: gpurun -- 'bash tools/collect_counters.sh r02'
+# For the dominant kernel of every BASELINE config: rocprofv3 --kernel-trace --stats, then PMC passes in runs of their own
+# (SQ counters; FETCH_SIZE; WRITE_SIZE -- the TCC pair does not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"),
+# each over `python3 bench.py ... --single-mode --no-cpu` (the program directly behind `--`).
+# Output: gpurun_out/ctr_<tag>/<config>/{kt,sq,fetch,write}/... ; tools/summarize_counters.py turns it into
+# profiles/<tag>_counters.json (what bench.py reads) and copies the kernel-stats csvs.
+tag=${1:-r02}
+out=$PWD/gpurun_out/ctr_$tag
+mkdir -p $out
+cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
+SQ2="SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAVES"
+run() {
+  name=$1; shift
+  mkdir -p $out/$name
+  echo "$@" > $out/$name/args.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/kt -- python3 bench.py --steps 40 --warmup 4 --no-cpu --single-mode "$@" > $out/$name/bench_under_rocprof.json 2> $out/$name/kt.err
+  rocprofv3 --pmc $SQ --output-format csv -d $out/$name/sq -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/sq.err
+  rocprofv3 --pmc $SQ2 --output-format csv -d $out/$name/sq2 -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/sq2.err
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$name/fetch -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/fetch.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$name/write -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/write.err
+}
+sel=${2:-all}
+[ $sel = all -o $sel = cfg2 ] && run cfg2_pitch_s256
+[ $sel = all -o $sel = cfg3 ] && run cfg3_voc_s256 --mode voc
+[ $sel = all -o $sel = cfg4 ] && run cfg4_both_s1024 --mode both --streams 1024
+[ $sel = all -o $sel = cfg5 ] && run cfg5_both_s512 --cfg5 --mode both --streams 512
+[ $sel = all -o $sel = cfg2x ] && run cfg2_pitch_s256_exact --iir exact
+python3 tools/summarize_counters.py $out $tag

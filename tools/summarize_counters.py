@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Summarises tools/collect_counters.sh's output tree into profiles/<tag>_counters.json (per kernel build and workload:
+rocprofv3 kernel-trace average duration, SQ counters per launch, HBM bytes per launch) and copies the per-config
+kernel-stats csv next to it.  Run on the box that collected them (or here, on the merged gpurun_out/ tree).
+
+HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+gfx950 (TCC_EA0_RDREQ tallied at 64 B per 128-B request); the uncorrected sum is kept beside it."""
+import csv
+import glob
+import json
+import os
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def counter_means(d):
+    """{kernel name: {counter: mean per dispatch, 'n': dispatches}} over our kernels in one --pmc output tree."""
+    res = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if not k.startswith("vp_k_"):
+                continue
+            acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            res.setdefault(k, {}).update({c: statistics.mean(v) for c, v in cs.items()})
+            res[k]["n"] = max(len(v) for v in cs.values())
+    return res
+
+
+def kernel_stats(d):
+    res = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Name"].split("(")[0]
+            if k.startswith("vp_k_"):
+                res[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                          "max_us": float(r["MaxNs"]) / 1e3}
+        return res, f
+    return res, None
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    import bench
+    summary = {"note": "tools/collect_counters.sh: per config `rocprofv3 --kernel-trace --stats`, then `--pmc` passes in runs of their own "
+                       "(SQ x2, FETCH_SIZE, WRITE_SIZE) over `python3 bench.py --single-mode --no-cpu <args>`; means per dispatch. "
+                       "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); "
+                       "SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles summed over waves.",
+               "kernel_source_hash": bench.kernel_source_hash(), "kernels": {}, "configs": {}}
+    prof = os.path.join(ROOT, "profiles")
+    for cdir in sorted(glob.glob(os.path.join(out, "*", ""))):
+        name = os.path.basename(os.path.dirname(cdir))
+        try:
+            line = json.loads(open(os.path.join(cdir, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError):
+            continue
+        cfg = line["config"]
+        mono = cfg["input"].startswith("mono")
+        wkey = f"{'cfg5' if 'configs[4]' in cfg['workload'] else 'cfg'}/{cfg['mode']}{'-mono' if mono else ''}/S{cfg['streams_per_gpu']}/N{cfg['block']}/{cfg['iir_mode']}/{cfg['yin_mode']}"
+        ks, ksf = kernel_stats(os.path.join(cdir, "kt"))
+        if ksf:
+            shutil.copy(ksf, os.path.join(prof, f"{tag}_{name}_kernel_stats.csv"))
+        shutil.copy(os.path.join(cdir, "bench_under_rocprof.json"), os.path.join(prof, f"{tag}_{name}_bench_under_rocprof.json"))
+        ctr = {}
+        for sub in ("sq", "sq2", "fetch", "write"):
+            for k, v in counter_means(os.path.join(cdir, sub)).items():
+                ctr.setdefault(k, {}).update({c: x for c, x in v.items() if c != "n"})
+                ctr[k][f"n_{sub}"] = v["n"]
+        summary["configs"][name] = {"args": open(os.path.join(cdir, "args.txt")).read().strip(), "workload_key": wkey,
+                                    "value_under_rocprof": line["value"], "kernel_us_hip_events": line["kernel_us"]}
+        for k in sorted(set(ks) | set(ctr)):
+            e = dict(ctr.get(k, {}))
+            e.update({"rocprof_" + a: b for a, b in ks.get(k, {}).items()})
+            if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+                e["hbm_bytes_per_launch_uncorrected"] = (e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+            if e.get("SQ_WAVE_CYCLES"):
+                e["valu_active_over_wave_cycles"] = e.get("SQ_ACTIVE_INST_VALU", 0.0) / e["SQ_WAVE_CYCLES"]
+                e["lds_wait_over_wave_cycles"] = e.get("SQ_WAIT_INST_LDS", 0.0) / e["SQ_WAVE_CYCLES"]
+            summary["kernels"][f"{k}@{wkey}"] = e
+    dst = os.path.join(prof, f"{tag}_counters.json")
+    json.dump(summary, open(dst, "w"), indent=1, sort_keys=True)
+    print("wrote", dst)
+    for k, e in summary["kernels"].items():
+        print(k, {a: round(b, 1) if isinstance(b, float) else b for a, b in e.items() if a in (
+            "rocprof_avg_us", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "valu_active_over_wave_cycles", "lds_wait_over_wave_cycles",
+            "SQ_LDS_BANK_CONFLICT", "hbm_bytes_per_launch")})
+
+
+if __name__ == "__main__":
+    main()

@@ -1988,7 +1988,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
                 for (; spin < (1 << 22) &&
                      __hip_atomic_load(&L.ishare[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xcGen; spin++)
                     __builtin_amdgcn_s_sleep(1);         // wave 5 finished long ago; bounded so that a bug cannot hang the GPU
-                if (spin == (1 << 22)) { L.ishare[1] = 1; if ((tid & 63) == 0) atomicAdd(&d.dbg[61], 1ULL); }   // never seen; falls back
+                if (spin == (1 << 22)) { L.ishare[1] = 1; if ((tid & 63) == 0) atomicAdd(&d.dbg[59], 1ULL); }   // never seen; falls back
                 const lds_f64 *P = L.eF;
                 const double E0 = P[g.F] - P[0];
                 if (ty == 0) L.xcA[0] = P[g.F + g.tauMax];
@@ -2126,6 +2126,9 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     if (!yin_pick(g, d, L, st, tid, nt, xcCert)) {
         // a comparison of the certified form was too close to call (about once in 1e9 frames; always with the
         // diagnostic mode 3): the frame again, in the reference's arithmetic
+        // (barrier first: yin_pick's verdict is read from ishare[1] by every thread; a wavefront that got there after the
+        // reset below would take the frame for certified, skip this branch and run one barrier out of step with the others)
+        __syncthreads();
         if (tid == 0) { L.ishare[0] = INT_MAX; L.ishare[1] = 0; atomicAdd(&d.dbg[63], 1ULL); }
         yin2_exact_waves(g, L, g.toKeep - g.tauMax, tid, 1, yWaves, yNPairs);
         __syncthreads();
@@ -2155,7 +2158,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
             int spin = 0;
             for (; spin < (1 << 22) && __hip_atomic_load(L.lpcFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != xcGen; spin++)
                 __builtin_amdgcn_s_sleep(1);
-            if (spin == (1 << 22) && (tid & 63) == 0) atomicAdd(&d.dbg[61], 1ULL);
+            if (spin == (1 << 22) && (tid & 63) == 0) atomicAdd(&d.dbg[60], 1ULL);
             for (int j = 4 * (rank * WAVE + (tid & 63)); j < g.toKeep + g.F; j += 4 * nWork * WAVE)
                 fir4((const lds_f64 *)L.xs, a, order, j, g.toKeep + g.F, L.eF);
         }

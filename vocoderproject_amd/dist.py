@@ -24,14 +24,17 @@ def shard_sizes(n_streams, world):
     return [shard_range(n_streams, r, world)[1] - shard_range(n_streams, r, world)[0] for r in range(world)]
 
 
-def scatter_streams(x_root, n_streams, tail_shape, dtype, device, src=0, group=None):
-    """Rank `src` holds x_root [n_streams, *tail_shape]; every rank returns its own shard.
+def scatter_streams(x_root, n_streams, tail_shape, dtype, device, src=0, group=None, out=None, async_op=False):
+    """Rank `src` holds x_root [n_streams, *tail_shape]; every rank returns its own shard (into `out` when given).
+    async_op: returns (shard, works) without waiting -- `w.wait()` on each work before the shard is read (under RCCL
+    that orders the current stream behind the transfer, it does not block the host): double-buffered exchanges.
 
     Point-to-point (no padding needed for ragged shards), issued as ONE batch_isend_irecv group: under RCCL every
     peer pair otherwise sets its channel up lazily, one after the other.  `src` is a rank OF THE GROUP."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_streams, rank, world)
-    mine = torch.empty((hi - lo, *tail_shape), dtype=dtype, device=device)
+    mine = out if out is not None else torch.empty((hi - lo, *tail_shape), dtype=dtype, device=device)
+    assert tuple(mine.shape) == (hi - lo, *tail_shape)
     ops = []
     if rank == src:
         for r in range(world):
@@ -42,8 +45,8 @@ def scatter_streams(x_root, n_streams, tail_shape, dtype, device, src=0, group=N
                 ops.append(dist.P2POp(dist.isend, x_root[rlo:rhi].contiguous(), _global_rank(group, r), group))
     elif hi > lo:
         ops.append(dist.P2POp(dist.irecv, mine, _global_rank(group, src), group))
-    _run(ops)
-    return mine
+    works = _run(ops, async_op)
+    return (mine, works) if async_op else mine
 
 
 def _global_rank(group, r):
@@ -51,15 +54,18 @@ def _global_rank(group, r):
     return r if group is None else dist.get_global_rank(group, r)
 
 
-def _run(ops):
-    if ops:
-        for q in dist.batch_isend_irecv(ops):
+def _run(ops, async_op=False):
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if not async_op:
+        for q in works:
             q.wait()
+    return works
 
 
-def gather_streams(y_local, n_streams, dst=0, group=None, out=None):
+def gather_streams(y_local, n_streams, dst=0, group=None, out=None, async_op=False):
     """Inverse of scatter_streams: rank `dst` (of the group) returns [n_streams, *tail], the others None.
-    `out` (optional, on `dst`): a preallocated [n_streams, *tail] tensor to receive into."""
+    `out` (optional, on `dst`): a preallocated [n_streams, *tail] tensor to receive into.
+    async_op: returns (result, works) without waiting (see scatter_streams)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     tail = tuple(y_local.shape[1:])
     if rank == dst:
@@ -72,9 +78,8 @@ def gather_streams(y_local, n_streams, dst=0, group=None, out=None):
                 out[rlo:rhi].copy_(y_local)
             elif rhi > rlo:
                 ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], _global_rank(group, r), group))
-        _run(ops)
-        return out
+        works = _run(ops, async_op)
+        return (out, works) if async_op else out
     lo, hi = shard_range(n_streams, rank, world)
-    if hi > lo:
-        _run([dist.P2POp(dist.isend, y_local.contiguous(), _global_rank(group, dst), group)])
-    return None
+    works = _run([dist.P2POp(dist.isend, y_local.contiguous(), _global_rank(group, dst), group)], async_op) if hi > lo else []
+    return (None, works) if async_op else None
