@@ -214,6 +214,12 @@ def main():
     if (args.gpus > 1 or os.environ.get("VP_BENCH_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # nothing above touched a GPU
 
+    # stdout carries ONE JSON line and nothing else: libraries that write to the C-level stdout (RCCL prints a version
+    # banner there, flushed when the process exits, i.e. after the line) get stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from vocoderproject_amd import BatchVocoderProcessor
@@ -492,7 +498,7 @@ def main():
             out["stft_kernel"] = stft_figure(dev, S)
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(mode, N, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

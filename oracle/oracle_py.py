@@ -89,6 +89,10 @@ def lib():
         L.vpo_kat_marks_seq.argtypes = [dp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_double,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(C.c_int), dp]
+        ip = C.POINTER(C.c_int)
+        L.vpo_kat_psola.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, ip, C.c_int, ip, C.c_int, dp]
+        L.vpo_kat_pitch_filters.argtypes = [dp, C.c_int, C.c_int, C.c_double, dp, C.c_int, dp, dp, dp]
+        L.vpo_kat_voc_window.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, dp, dp, dp, dp]
         L.vpo_gain_to_db.argtypes = [C.c_double]
         L.vpo_gain_to_db.restype = C.c_double
         L.vpo_db_to_gain_f.argtypes = [C.c_float]
@@ -324,3 +328,46 @@ def kat_marks_seq(x, periods, F=1024, H=768, fs=44100.0):
     an = [list(m[f * MARK_CAP: f * MARK_CAP + cnt[f]]) for f in range(nf)]
     st = [list(sm[f * MARK_CAP: f * MARK_CAP + scnt[f]]) for f in range(nf)]
     return an, st, list(pn), beta
+
+
+def kat_psola(e, T, beta, an_marks, st_marks, F=1024, H=768, fs=44100.0):
+    """PitchProcess::psola + interp for one frame, all synthesis marks at once.  e: eFrame[0 .. toKeep + F) with toKeep = F.
+    Returns (outEFrame [F], number of Q2/Q3 paths taken)."""
+    e = np.ascontiguousarray(e, np.float64)
+    assert e.shape == (2 * F,)
+    an = np.ascontiguousarray(an_marks, np.int32)
+    st = np.ascontiguousarray(st_marks, np.int32)
+    out = np.zeros(F)
+    ip = C.POINTER(C.c_int)
+    rc = lib().vpo_kat_psola(_dp(e), F, H, float(fs), int(T), float(beta), an.ctypes.data_as(ip), len(an), st.ctypes.data_as(ip), len(st), _dp(out))
+    if rc < 0:
+        raise ValueError(f"kat_psola rc={rc}")
+    return out, rc
+
+
+def kat_pitch_filters(x, a, out_e, F=1024, H=768, fs=44100.0):
+    """filterFIR(-toKeep, toKeep + F, 0) of x [toKeep + F] and the chunked filterIIR of out_e [F], coefficients a[0..p]."""
+    x = np.ascontiguousarray(x, np.float64)
+    a = np.ascontiguousarray(a, np.float64)
+    out_e = np.ascontiguousarray(out_e, np.float64)
+    assert x.shape == (2 * F,) and out_e.shape == (F,)
+    e, y = np.zeros(2 * F), np.zeros(F)
+    rc = lib().vpo_kat_pitch_filters(_dp(x), F, H, float(fs), _dp(a), len(a) - 1, _dp(out_e), _dp(e), _dp(y))
+    if rc:
+        raise ValueError(f"kat_pitch_filters rc={rc}")
+    return e, y
+
+
+def kat_voc_window(voice, synth, hop, a_v, a_s):
+    """One vocoder window from a fresh state with given coefficient vectors: (eVoice, eSynth, (EeV, EeS), g, out)."""
+    voice = np.ascontiguousarray(voice, np.float64)
+    synth = np.ascontiguousarray(synth, np.float64)
+    a_v = np.ascontiguousarray(a_v, np.float64)
+    a_s = np.ascontiguousarray(a_s, np.float64)
+    W = len(voice)
+    ev, es, out, EE, g = np.zeros(W), np.zeros(W), np.zeros(W), np.zeros(2), np.zeros(1)
+    rc = lib().vpo_kat_voc_window(_dp(voice), _dp(synth), W, int(hop), _dp(a_v), len(a_v) - 1, _dp(a_s), len(a_s) - 1, _dp(ev), _dp(es),
+                                  _dp(EE), _dp(g), _dp(out))
+    if rc:
+        raise ValueError(f"kat_voc_window rc={rc}")
+    return ev, es, EE, float(g[0]), out

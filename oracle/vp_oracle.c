@@ -1135,6 +1135,90 @@ int vpo_kat_marks_seq(const double *x, int nFrames, const int *periods, int F, i
     return 0;
 }
 
+/* KAT hook: PitchProcess::psola (:665-741) + interp (:842-870) + getClosestAnMarkIdx (:788-831) for ONE frame, every
+ * synthesis mark in one go (nChunk = chunksPerFrame - 1, so that the scheduling test :685 passes all of them; with
+ * N = F the completeness tests :800-818 hold for every mark of the frame).  e = eFrame[0 .. toKeep + F) (frame position
+ * p <-> e[toKeep + p], :698), voiced frame of period T, shift factor beta.  outE [F] receives outEFrame. */
+int vpo_kat_psola(const double *e, int F, int H, double fs, int T, double beta, const int *an, int nAn, const int *st, int nSt,
+                  double *outE)
+{
+    if (nAn > VPO_MARK_CAP || nSt > VPO_MARK_CAP || T < 1) return -1;
+    vpo *o = vpo_create();
+    if (!o) return -1;
+    int rc = vpo_prepare_explicit(o, fs, F, F, H, 512, 128);
+    if (rc) { vpo_destroy(o); return rc; }
+    if (T > o->tauMax) { vpo_destroy(o); return -1; }
+    memset(o->eFrame, 0, (size_t)o->eFrameLen * sizeof(double));
+    memcpy(o->eFrame, e, (size_t)(o->toKeep + F) * sizeof(double));
+    memset(o->outEFrame, 0, (size_t)F * sizeof(double));
+    o->pStart = 0; o->nChunk = o->chunksPerFrame - 1;
+    o->period = T; o->pitch = fs / T; o->beta = beta;
+    o->nAnMarksOv = 0;
+    for (int i = 0; i < nAn; i++) o->anMarks.v[i] = an[i];
+    o->anMarks.n = nAn;
+    for (int i = 0; i < nSt; i++) o->stMarks.v[i] = st[i];
+    o->stMarks.n = nSt;
+    o->stMarkIdx = 0;
+    pitch_psola(o);
+    memcpy(outE, o->outEFrame, (size_t)F * sizeof(double));
+    rc = (int)(o->ub[0] + o->ub[1]);                                          /* > 0: a Q2/Q3 path was taken */
+    vpo_destroy(o);
+    return rc;
+}
+
+/* KAT hook: the pitch path's two filters with GIVEN coefficients a[0..order].  x [toKeep + F] = voice samples
+ * idx -toKeep .. F-1; eOut [toKeep + F] <- filterFIR(-toKeep, toKeep + F, 0) (:280-302, as processChunkStart :235
+ * calls it); yOut [F] <- filterIIR (:307-322) of outE [F], chunk after chunk with the state carried through yFrame. */
+int vpo_kat_pitch_filters(const double *x, int F, int H, double fs, const double *a, int order, const double *outE,
+                          double *eOut, double *yOut)
+{
+    vpo *o = vpo_create();
+    if (!o) return -1;
+    if (vpo_set_param(o, "lpcPitch", (float)order)) { vpo_destroy(o); return -1; }
+    int rc = vpo_prepare_explicit(o, fs, F, F, H, 512, 128);
+    if (rc) { vpo_destroy(o); return rc; }
+    for (int i = 0; i < o->toKeep + F; i++)
+        o->voice[(o->currCounter + (i - o->toKeep) + o->inSize) % o->inSize] = x[i];
+    o->pStart = 0;
+    memset(o->a, 0, sizeof o->a);
+    memcpy(o->a, a, (size_t)(order + 1) * sizeof(double));
+    memset(o->eFrame, 0, (size_t)o->eFrameLen * sizeof(double));
+    pitch_filter_fir(o, -o->toKeep, o->toKeep + F, 0);
+    memcpy(eOut, o->eFrame, (size_t)(o->toKeep + F) * sizeof(double));
+    memcpy(o->outEFrame, outE, (size_t)F * sizeof(double));
+    memset(o->yFrame, 0, (size_t)F * sizeof(double));
+    for (o->nChunk = 0; o->nChunk < o->chunksPerFrame; o->nChunk++) pitch_filter_iir(o);
+    memcpy(yOut, o->yFrame, (size_t)F * sizeof(double));
+    vpo_destroy(o);
+    return 0;
+}
+
+/* KAT hook: one vocoder window with GIVEN coefficient vectors, from a fresh state (empty energy histories): the two
+ * residuals and their energies (filterFIR :235-251), the gain (:264-275) and the all-pole output before the synthesis
+ * window (:277-286).  voice/synth [W] are the raw samples of the window (the analysis window is applied inside). */
+int vpo_kat_voc_window(const double *voice, const double *synth, int W, int hop, const double *aV, int orderV, const double *aS,
+                       int orderS, double *eV, double *eS, double *EE, double *g, double *out)
+{
+    vpo *o = vpo_create();
+    if (!o) return -1;
+    int rc = vpo_prepare_explicit(o, 44100.0, W, 1024, 768, W, hop);
+    if (rc) { vpo_destroy(o); return rc; }
+    for (int i = 0; i < W; i++) {
+        o->voice[(o->currCounter + i) % o->inSize] = voice[i];
+        o->synth[0][(o->currCounter + i) % o->inSize] = synth[i];
+    }
+    o->vStart = 0;
+    voc_filter_fir(o, 0, o->eV, aV, orderV, &o->EeV);
+    voc_filter_fir(o, 1, o->eS, aS, orderS, &o->EeS);
+    voc_filter_iir(o, aV, orderV);
+    memcpy(eV, o->eV, (size_t)W * sizeof(double));
+    memcpy(eS, o->eS, (size_t)W * sizeof(double));
+    memcpy(out, o->vOut, (size_t)W * sizeof(double));
+    EE[0] = o->EeV; EE[1] = o->EeS; *g = o->g;
+    vpo_destroy(o);
+    return 0;
+}
+
 int vpo_get_geometry(const vpo *o, int out[12])
 {
     out[0] = o->N; out[1] = o->F; out[2] = o->H; out[3] = o->C; out[4] = o->W; out[5] = o->h;

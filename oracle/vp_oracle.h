@@ -16,14 +16,26 @@
  *       and runs of frames: continuation through the overlap, unvoiced extrapolation, restart),
  *       synthesis pitch marks over the same runs (beta from the note table, new period,
  *       continuity rules), the PSOLA Hann(2T+1) window, sine window, chromatic note table.
+ *     - pinned, round 2 (tests/golden/filter_psola_vectors.npz, same route: gen_filter_psola_vectors.py ran methods.py and
+ *       the scipy.signal.lfilter calls of the reference's notebook, cells 9 and 25):
+ *         PSOLA -- grain extraction around the closest analysis mark, Hann(2T+1) with the first/last half-windowing,
+ *           x-positions mark + (j - T)/beta, linear interpolation onto the integer grid, accumulation in mark order
+ *           (psola/interp/getClosestAnMarkIdx vs methods.pitch_shift on whole frames, beta from 0.97 to 2: equal to 3e-16;
+ *           the one sample the plugin drops when the last grain ends on an integer is asserted as such);
+ *         the pitch path's filterFIR over [-toKeep, F) and chunked filterIIR vs lfilter(a,[1],.) / lfilter([1],a,.),
+ *           a = methods.lpc, orders 2..100 (1e-9 of peak: lfilter sums in transposed-form order);
+ *         the vocoder's two residuals, energies, gain and all-pole output of a window vs the same calls, geometries
+ *           512/128, 1024/256, 2048/512, 512/256;
+ *         the note tables of the 12 major keys and the nearest note on a 600-point pitch grid vs
+ *           methods.build_notes_vector(key) / argmin.
  *     - pinned (SURVEY.md Appendix A / section 3.1 known answers recorded from a survey-session run of the
  *       compiled reference): Notes::getClosestFreq KATs, prepareToPlay geometry (latency,
  *       inSize, outSize, tauMax at 44.1 kHz and 48 kHz), "ch2 returns 0".
- *     - PARITY UNPINNED: end-to-end processBlock() output, the mark branches methods.py does not
- *       share with the plugin (voiced->voiced without marks in the overlap, getClosestAnMarkIdx),
- *       PSOLA grain placement/interpolation (methods.pitch_shift works per frame, the plugin per
- *       chunk), and the rest of the JUCE arithmetic surface (getRMSLevel, Decibels), which is
- *       restated from JUCE 5.4.x documented semantics.
+ *     - PARITY UNPINNED: end-to-end processBlock() output as a whole (every stage of it is pinned above except the
+ *       ones listed here), the mark branches methods.py does not share with the plugin (voiced->voiced without marks
+ *       in the overlap; getClosestAnMarkIdx's incomplete-grain fallbacks :804-812 and the Q2/Q3 reads), the chunk
+ *       scheduling of PSOLA (Q5: the notebook works per frame), MyBuffer's ring/counter arithmetic, and the JUCE
+ *       arithmetic surface (getRMSLevel, Decibels, ScopedNoDenormals), restated from JUCE 5.4.x documented semantics.
  *
  * Every function cites the reference file:line it restates (paths relative to
  * /root/reference/Source/).
@@ -104,6 +116,13 @@ void vpo_yin_temp_linear(const double *x, int frameLen, int tauMax, double *yinT
 /* PitchProcess.cpp:411-448 threshold walk on a given yinTemp (tauMax+1 entries readable); returns period (0 = unvoiced) */
 int vpo_yin_pick(const double *yinTemp, int tauMax, double fS, double fMax, double yinTol);
 /* KAT hook: PitchProcess.cpp:455-567 for a frame following an unvoiced one; returns the mark count */
+/* KAT hooks for the oracle pins of round 2 (tests/golden/gen_filter_psola_vectors.py; see vp_oracle.c) */
+int vpo_kat_psola(const double *e, int F, int H, double fs, int T, double beta, const int *an, int nAn, const int *st, int nSt,
+                  double *outE);
+int vpo_kat_pitch_filters(const double *x, int F, int H, double fs, const double *a, int order, const double *outE,
+                          double *eOut, double *yOut);
+int vpo_kat_voc_window(const double *voice, const double *synth, int W, int hop, const double *aV, int orderV, const double *aS,
+                       int orderS, double *eV, double *eS, double *EE, double *g, double *out);
 int vpo_kat_pitch_marks(const double *x, int F, int H, double fs, int period, int *marksOut);
 int vpo_kat_marks_seq(const double *x, int nFrames, const int *periods, int F, int H, double fs, int *marksOut, int *countsOut,
                       int *stMarksOut, int *stCountsOut, int *periodNewOut, double *betaOut);
