@@ -68,8 +68,8 @@ def usable_cores():
 def kernel_source_hash():
     """sha256 over what the kernels are built from: a counter file measured on other sources is not this build's."""
     h = hashlib.sha256()
-    for rel in ("vocoderproject_amd/csrc/vp_kernels.hip", "vocoderproject_amd/csrc/vp_common.h", "vocoderproject_amd/csrc/vp_kernels.h",
-                "vocoderproject_amd/build.py"):
+    for rel in ("vocoderproject_amd/csrc/vp_kernels.hip", "vocoderproject_amd/csrc/vp_voc2.hip", "vocoderproject_amd/csrc/vp_common.h",
+                "vocoderproject_amd/csrc/vp_kernels.h", "vocoderproject_amd/csrc/vp_voc2.h", "vocoderproject_amd/build.py"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--exchange", action="store_true",
                     help="also time SURVEY 8(e)'s exchange: rank 0 holds the whole batch; per step scatter -> processBlock -> gather "
                          "(double-buffered, RCCL point-to-point).  On by default when N > 1.")
+    ap.add_argument("--voc-path", default="auto", choices=["auto", "workgroup", "batched"],
+                    help="vocoder implementation (vp_set_vocoder_path): one workgroup per stream, or the lane-per-window pipeline "
+                         "(auto: the pipeline from 3072 windows per block on)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -262,6 +265,7 @@ def main():
             q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"))
             q.prepareToPlay(FS, N, S_)
         q.set_yin_mode(args.yin)
+        q.set_vocoder_path(args.voc_path)
         return q
 
     p = make_processor(mode, S)

@@ -148,6 +148,18 @@ int vp_process_blocks(vp_handle *h, const float *in, float *out, int n_blocks);
 int vp_set_iir_mode(vp_handle *h, int mode);
 int vp_get_iir_mode(const vp_handle *h);
 
+/* Which implementation of the vocoder (VocoderProcess::process) a block runs.  Same results (bit-identical in
+ * VP_IIR_EXACT mode), different mapping onto the GPU:
+ * VP_VOC_WORKGROUP: one workgroup per stream, one wavefront per window (vp_k_vocoder / vp_k_vocoder_lite);
+ * VP_VOC_BATCHED: a pipeline of small kernels in which one LANE owns one window (vp_voc2.hip) -- pays when a block of the
+ *   batch has thousands of windows; LPC orders up to 48, at most 64 windows per stream and block, else the call falls back;
+ * VP_VOC_AUTO (default): batched from 3072 windows per block on. */
+#define VP_VOC_AUTO 0
+#define VP_VOC_WORKGROUP 1
+#define VP_VOC_BATCHED 2
+int vp_set_vocoder_path(vp_handle *h, int path);
+int vp_get_vocoder_path(const vp_handle *h);
+
 /* How the YIN difference function (PitchProcess.cpp:350-403) and the pitch frame's LPC autocorrelation
  * (LPC.cpp:44-97) are evaluated.
  * VP_YIN_DIRECT (default): the reference's O(F tau) sums in its own order; decisions bit-identical.

@@ -18,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libvp_amd.so")
-SOURCES = ["vp_kernels.hip", "vp_capi.hip"]
-DEPS = SOURCES + ["vp_common.h", "vp_kernels.h"]
+SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_capi.hip"]
+DEPS = SOURCES + ["vp_common.h", "vp_kernels.h", "vp_voc2.h"]
 ARCH = "gfx950"
 NUM_TUS = 5          # groups of kernels in vp_kernels.hip (VP_TU)
 
@@ -66,14 +66,32 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     groups = [0] if not (stamps or poison) else list(range(1, NUM_TUS + 1))
     with tempfile.TemporaryDirectory(prefix="vp_build_") as tmp:
         jobs = [(os.path.join(CSRC, "vp_kernels.hip"), os.path.join(tmp, f"k{k}.o"), [f"-DVP_TU={k}"]) for k in groups]
+        jobs.append((os.path.join(CSRC, "vp_voc2.hip"), os.path.join(tmp, "voc2.o"), []))     # the batched vocoder pipeline (includes vp_kernels.hip's helpers)
         jobs.append((os.path.join(CSRC, "vp_capi.hip"), os.path.join(tmp, "capi.o"), []))
 
         def compile_one(job):
+            # objects are cached by a hash of everything that goes into them (the big translation unit takes minutes)
+            import hashlib
             src, obj, extra = job
             cmd = common + extra + ["-c", src, "-o", obj]
+            hsh = hashlib.sha256(" ".join(cmd[:-1]).replace(tmp, "").encode())
+            deps = {"vp_kernels.hip": ["vp_kernels.hip", "vp_common.h"],
+                    "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"]}.get(os.path.basename(src))
+            if deps is None:
+                deps = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.basename(src), os.path.join(ROOT, "include", "vp_amd.h")]
+            for dep in deps:
+                with open(dep if os.path.isabs(dep) else os.path.join(CSRC, dep), "rb") as f:
+                    hsh.update(f.read())
+            cache = os.path.join(HERE, ".build_cache")
+            os.makedirs(cache, exist_ok=True)
+            cached = os.path.join(cache, os.path.basename(obj) + "." + hsh.hexdigest()[:20])
+            if os.path.exists(cached) and not os.environ.get("VP_NO_OBJ_CACHE"):
+                shutil.copy(cached, obj)
+                return obj
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            shutil.copy(obj, cached)
             return obj
 
         with ThreadPoolExecutor(len(jobs)) as ex:

@@ -19,6 +19,7 @@
 
 #include "../../include/vp_amd.h"
 #include "vp_kernels.h"
+#include "vp_voc2.h"
 
 struct vp_handle {
     int device = 0;
@@ -38,6 +39,9 @@ struct vp_handle {
     int *dMapAll = nullptr;                     // [S] device storage of the cohorts' maps, back to back
     std::vector<int> mapHost;                   // staging for its upload
     bool poisoned = false;                      // a HIP call failed inside a process call: host counters and device state may disagree
+    // the batched lane-per-window vocoder pipeline (vp_voc2.hip): scratch, the orders it must cover, and who picks it
+    VpV2 v2;
+    int vocPath = VP_VOC_AUTO, oVmax = 0, oSmax = 0, nWinMax = 0;
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
@@ -138,9 +142,33 @@ static int voc_lite_slots(const vp_handle *h, bool iirFast, int nw)
     return vp_voc_lds_bytes(h->g.W, nl) <= (size_t)(80 * 1024 - 512) ? nl : 0;
 }
 
+// The batched pipeline pays when the launch has thousands of windows (a lane each); it covers LPC orders up to
+// V2_ORDER_MAX and blocks of up to 64 windows per stream.  VP_VOC_BATCHED forces it wherever it is able to run.
+#define VP_V2_MIN_WINDOWS 3072
+static bool voc_batched_for(const vp_handle *h, int nStreams, int nWin, int oV, int oS)
+{
+    if (!h->v2.lin || h->vocPath == VP_VOC_WORKGROUP || nWin < 1 || nWin > 64) return false;
+    if (oV > V2_ORDER_MAX || oS > VP_ORDER_MAX_SYNTH || oV < 2 || oS < 2) return false;
+    return h->vocPath == VP_VOC_BATCHED || (size_t)nStreams * nWin >= VP_V2_MIN_WINDOWS;
+}
+static bool voc_batched(const vp_handle *h, int nStreams, int nWin) { return voc_batched_for(h, nStreams, nWin, h->oVmax, h->oSmax); }
+
+extern "C" int vp_set_vocoder_path(vp_handle *h, int path)
+{
+    if (!h || path < VP_VOC_AUTO || path > VP_VOC_BATCHED) return VP_ERR_INVALID_ARG;
+    h->vocPath = path;
+    return VP_OK;
+}
+extern "C" int vp_get_vocoder_path(const vp_handle *h) { return h ? h->vocPath : VP_ERR_INVALID_ARG; }
+
 extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
+    {
+        int oV = 0, oS = 0;
+        for (const auto &q : h->sparams) { oV = std::max(oV, q.lpcVoice); oS = std::max(oS, q.lpcSynth); }
+        if (voc_batched_for(h, h->g.S, h->nWinMax, oV, oS)) return "vp_k_v2_pipeline";      // (orders as the next block will see them)
+    }
     return voc_lite_slots(h, h->iirMode == VP_IIR_FAST, h->vocWaves) ? "vp_k_vocoder_lite" : "vp_k_vocoder";
 }
 
@@ -524,6 +552,24 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         RC(dev_upload(h, &d.twIm, twi));
     }
     RC(dev_alloc(h, &h->dMapAll, (size_t)S));
+    {   // scratch of the batched vocoder pipeline (a block has at most ceil(N / hop) windows per stream)
+        memset(&h->v2, 0, sizeof h->v2);
+        h->nWinMax = (N + hop - 1) / hop;
+        const size_t NW = (size_t)S * h->nWinMax;
+        h->v2.span = (h->nWinMax - 1) * hop + W;
+        if (h->nWinMax <= 64 && h->v2.span < g.inSize && vp_v2_init() == 0) {
+            RC(dev_alloc(h, &h->v2.lin, (size_t)S * 2 * h->v2.span + 64));      // (+ padding: the autocorrelation reads a few samples ahead)
+            RC(dev_alloc(h, &h->v2.rV, NW * V2_RV_STRIDE, false));
+            RC(dev_alloc(h, &h->v2.aV, NW * V2_RV_STRIDE, false));
+            RC(dev_alloc(h, &h->v2.rS, NW * V2_RS_STRIDE, false));
+            RC(dev_alloc(h, &h->v2.aS, NW * V2_RS_STRIDE, false));
+            RC(dev_alloc(h, &h->v2.eV, NW * W));
+            RC(dev_alloc(h, &h->v2.eS, NW * W));
+            RC(dev_alloc(h, &h->v2.EE, NW * 2));
+            h->v2.nSlices = (W + V2_FIR_SLICE - 1) / V2_FIR_SLICE;
+            RC(dev_alloc(h, &h->v2.EEp, NW * 2 * h->v2.nSlices));
+        }
+    }
     RC(dev_alloc(h, &h->stageIn, (size_t)S * 3 * N, false));
     RC(dev_alloc(h, &h->stageOut, (size_t)S * 3 * N, false));
     {   // PitchProcess::prepare initial members (:76-85): everything 0 except beta = 1
@@ -645,9 +691,11 @@ static int sync_stream_state(vp_handle *h, hipStream_t st)
     if (h->spDirty) {
         // orders, key, gains and the dry-path switches travel in each stream's device state (VpPitchState::sp);
         // rewritten here, stream-ordered in front of this block's kernels, whenever a set call changed them
+        h->oVmax = h->oSmax = 0;
         for (int i = 0; i < g.S; i++) {
             fill_stream_params(h->spHost[i], h->sparams[i]);
             h->spHost[i].shiftOn = h->shiftOn[i]; h->spHost[i].shiftBeta = h->shiftBeta[i];
+            h->oVmax = std::max(h->oVmax, h->sparams[i].lpcVoice); h->oSmax = std::max(h->oSmax, h->sparams[i].lpcSynth);
         }
         HIPCHK(h, hipMemcpy2DAsync(&h->d.pitch[0].sp, sizeof(VpPitchState), h->spHost.data(), sizeof(VpStreamParams),
                                    sizeof(VpStreamParams), (size_t)g.S, hipMemcpyHostToDevice, st));
@@ -708,7 +756,15 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             { ProfScope ps(h, st, 0); hipLaunchKernelGGL(vp_k_ingest_gate, dim3(co.n), dim3(256), 0, st, g, c, d, d_in); }
             { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, d, d_out); }
         } else {
-            if (runVoc) {
+            if (runVoc && voc_batched(h, co.n, c.nWin)) {
+                // large batches: the pipeline of lane-per-window kernels (vp_voc2.hip), ingest+gate in front, emit behind
+                VpCall cv = c;
+                cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
+                ProfScope ps(h, st, 1);
+                VpV2 v = h->v2;
+                v.nStreams = co.n; v.oVmax = h->oVmax; v.oSmax = h->oSmax;
+                vp_v2_launch(g, cv, d, v, d_in, d_out, st);
+            } else if (runVoc) {
                 VpCall cv = c;
                 cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
                 ProfScope ps(h, st, 1);

@@ -1,0 +1,27 @@
+// vp_voc2.h -- interface between vp_capi.hip and the batched lane-per-window vocoder pipeline (vp_voc2.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vp_common.h"
+
+#define V2_RV_STRIDE 104        // doubles per window for r / a of the voice (orders <= VP_ORDER_MAX)
+#define V2_RS_STRIDE 32         // ... of the side chain (orders <= VP_ORDER_MAX_SYNTH)
+#define V2_FIR_SLICE 64         // outputs of a window per wavefront of the residual kernel
+#define V2_ORDER_MAX 48         // largest LPC order the register-resident kernels are instantiated for
+
+// scratch of the pipeline, per handle.  NW = streams x windows per block; window w = (cohort-local stream) x nWin + j.
+struct VpV2 {
+    float *lin;                 // [S][2][span]   the block's samples per stream, linear: voice, side-chain channel 0
+    double *rV, *rS;            // [NW][V2_RV_STRIDE], [NW][V2_RS_STRIDE]   autocorrelations
+    double *aV, *aS;            // same shapes: A(z) coefficients
+    double *eV, *eS;            // [NW][W] residuals; eV is overwritten by the all-pole output
+    double *EE;                 // [NW][2] residual energies (voice, side chain)
+    double *EEp;                // [NW][2][nSlices] the same per 64-output slice of the residual kernel
+    int nSlices;
+    int nStreams;               // streams of this launch (the cohort)
+    int span;                   // floats per channel in lin
+    int oVmax, oSmax;           // largest lpcVoice / lpcSynth over the streams (the orders themselves are per stream)
+};
+
+int vp_v2_init();
+void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st);

@@ -1,0 +1,604 @@
+// vp_voc2.hip -- the LPC vocoder (VocoderProcess.cpp:173-297) for LARGE batches, as a pipeline of small kernels in
+// which one LANE owns one window instead of one wavefront (or workgroup) owning it.
+//
+// Why: with one workgroup per stream (vp_k_vocoder) every serial stretch of a window -- Levinson-Durbin, the two
+// ordered energy sums, the all-pole recursion -- runs on 64 lanes redundantly, and the one lane-parallel stretch that
+// dominates (the autocorrelation, lane = lag) is bound by LDS traffic.  Counters at 1024 streams (profiles/, round 2):
+// the vector ALUs are busy half of the kernel's time, i.e. the kernel is throughput-bound on instructions that are
+// 3-60x more numerous than the arithmetic needs.  A batch of S streams x nWin windows per block has thousands of
+// independent windows; giving each its own lane makes every instruction do 64 windows' worth of the reference's
+// arithmetic, in the reference's own order (each lane simply runs the reference's loops), with no LDS and no barriers:
+// operands stream from HBM/L2 into registers, uniform ones (the window function) through scalar registers.
+//
+//   stage      (fused behind ingest+gate) the samples the block's windows cover, linear per stream   [S][2][span] f32
+//   autocorr   lane = window, wave = 64 windows x L lags (biaisedAutoCorr, LPC.cpp:44-97)            -> r  [NW][.]
+//   levinson   lane = window (levinsonDurbin, LPC.cpp:107-148)                                       -> a  [NW][.]
+//   fir        lane = window, wave = 64 windows x 64 outputs (filterFIR, VocoderProcess.cpp:235-251) -> e  [NW][W]
+//   energy     lane = window: sum e^2 in order, 10-deep histories, gain (:250, :264-275)              -> g  [NW]
+//   iir        EXACT: lane = window, the reference's chain (:277-286); FAST: wave = window, block form -> out [NW][W]
+//   ola        workgroup = stream: gainVoc * out * stWindow added in window order (:291-295) [+ emit]
+//
+// Every kernel is bit-identical to vp_k_vocoder in VP_IIR_EXACT mode (tests/test_gpu_round2.py); in VP_IIR_FAST mode the
+// recursion is the block form the pitch kernel uses (tolerance-tested).  Citations: file:line under /root/reference/Source/.
+#define VP_TU 99                 // vp_kernels.hip's device helpers without any of its kernels
+#include "vp_kernels.hip"
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "vp_voc2.h"
+
+// ------------------------------------------------------------------------------------------------
+// window w of the launch -> (cohort-local stream b, window j of the block), stream id, gate
+struct V2Win { int b, j, s; bool live; };
+__device__ __forceinline__ V2Win v2_window(const VpCall &c, const VpDev &d, const VpV2 &v, int w)
+{
+    V2Win q;
+    const int NW = v.nStreams * c.nWin;
+    const int wc = min(w, NW - 1);
+    q.b = wc / c.nWin;
+    q.j = wc - q.b * c.nWin;
+    q.s = d.streamMap ? d.streamMap[q.b] : q.b;
+    q.live = w < NW && d.gate[q.s * 2 + 0] && d.gate[q.s * 2 + 1];       // VocoderProcess.cpp:199-204
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: the block's window span of every stream, linear (no ring wrap), voice and side-chain channel 0.
+// lin[b][ch][i] = sample at logical index vStart + i, i < (nWin - 1) h + W.
+__device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v)
+{
+    const int s = vp_stream(d), b = blockIdx.x;
+    const float *vr = d.voiceRing + (size_t)s * g.inSize;
+    const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
+    float *lv = v.lin + (size_t)b * 2 * v.span, *ls = lv + v.span;
+    const int n = (c.nWin - 1) * g.h + g.W;
+    int p0 = ring_pos(c.currCounter, c.vStart, g.inSize);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int p = p0 + i;
+        p -= (p >= g.inSize) ? g.inSize : 0;                              // n < inSize: one wrap at most
+        lv[i] = vr[p];
+        ls[i] = sr0[p];
+    }
+}
+
+__global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, VpDev d, VpV2 v, const float *__restrict__ in)
+{
+    if (c.fuseIngest) ingest_gate_block(g, c, d, in);                      // (ends with a barrier: the ring is visible)
+    v2_stage_block(g, c, d, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// autocorr: r[m] = (1/W) sum_{n < W-m} ((x[n] w[n]) * x[n+m]) * w[n+m], each lag its own left-to-right sum
+// (LPC.cpp:58-96: outer n, inner m).  Lane = window; the wave takes L consecutive lags [m0, m0+L) of the voice
+// (blockIdx.y < gV) or of the side chain.  The lane's L+7 samples x[n+m0 ..] slide through registers (eight steps per
+// trip, names rotate statically), the window function comes through scalar registers (uniform index).
+template <int L>
+__global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const int gV = (v.oVmax + L) / L;                                     // lag groups of the voice: ceil((oVmax + 1) / L)
+    const bool isS = (int)blockIdx.y >= gV;
+    const int m0 = (isS ? (int)blockIdx.y - gV : (int)blockIdx.y) * L;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const int W = g.W;
+    const float *__restrict__ x = v.lin + ((size_t)q.b * 2 + (isS ? 1 : 0)) * v.span + (size_t)q.j * g.h;
+    const double *__restrict__ win = d.vocWin;
+    double sum[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) sum[j] = 0.0;
+    // all L lags are inside the window while n + m0 + L - 1 < W
+    const int nAll = max(0, W - m0 - (L - 1));
+    const int nMain = nAll & ~7;
+    if (nMain > 0) {
+        double xr[L + 8];                                                   // x[n + m0 + q], q < L + 8 (the trip's eight steps)
+#pragma unroll
+        for (int t = 0; t < L; t++) xr[t] = (double)x[m0 + t];
+        // the trip's sixteen raw samples (eight for tmp = x[n] w[n], eight new ones for the sliding window) are requested one
+        // trip AHEAD: with about one wavefront per SIMD nothing else hides the memory latency
+        float fu[8], fx[8], gu[8], gx[8];
+        // (the last trip reads up to one sample past the window: inside the staged span, or its padding, and never used)
+#define V2_AC_LOAD(FU, FX, N) _Pragma("unroll") for (int t = 0; t < 8; t++) { FU[t] = x[(N) + t]; FX[t] = x[(N) + m0 + L + t]; }
+#define V2_AC_TRIP(FU, FX, N) { double u[8]; \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) { xr[L + t] = (double)FX[t]; u[t] = (double)FU[t] * win[(N) + t]; }   /* tmp, LPC.cpp:61 */ \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) { \
+            _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * xr[t + j]; p = p * win[(N) + t + m0 + j]; sum[j] += p; } } \
+        _Pragma("unroll") for (int t = 0; t < L; t++) xr[t] = xr[t + 8]; }
+        V2_AC_LOAD(fu, fx, 0)
+        for (int n = 0; n < nMain; n += 16) {
+            const bool more1 = n + 8 < nMain;
+            if (more1) { V2_AC_LOAD(gu, gx, n + 8) }
+            V2_AC_TRIP(fu, fx, n)
+            if (more1) {
+                if (n + 16 < nMain) { V2_AC_LOAD(fu, fx, n + 16) }
+                V2_AC_TRIP(gu, gx, n + 8)
+            }
+        }
+#undef V2_AC_LOAD
+#undef V2_AC_TRIP
+    }
+    for (int n = nMain; n < W - m0; n++) {                                  // the last steps: lags drop out one by one
+        const double u = (double)x[n] * win[n];
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            if (n < W - m0 - j) {
+                double p = u * (double)x[n + m0 + j];
+                p = p * win[n + m0 + j];
+                sum[j] += p;
+            }
+        }
+    }
+    if (q.live) {
+        double *r = (isS ? v.rS + (size_t)w * V2_RS_STRIDE : v.rV + (size_t)w * V2_RV_STRIDE);
+        const int top = isS ? VP_ORDER_MAX_SYNTH : VP_ORDER_MAX;
+#pragma unroll
+        for (int j = 0; j < L; j++)
+            if (m0 + j <= top) r[m0 + j] = sum[j] / (double)W;           // :93-96
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// levinson: lane = window, the reference's recursion as it stands (LPC.cpp:107-148) on per-lane columns in LDS
+// (a[k][lane], r[k][lane]: conflict-free).  The coefficient update is done on the pair (i, p - i) at once -- each new
+// value is old[i] - k * old[p - i], the same operands and operation as the reference's pass over a copy.
+// blockIdx.y = 0: voice (order sp.orderVoice), 1: side chain.  Dynamic LDS: 2 x (top + 1) x 64 doubles.
+__global__ __launch_bounds__(64) void vp_k_v2_levinson(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const bool isS = blockIdx.y != 0;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const int top = isS ? v.oSmax : v.oVmax;                                // wave-uniform bound of the orders in this launch
+    lds_f64 *A = (lds_f64 *)smem + lane, *R = A + (size_t)(top + 1) * WAVE;  // column of this lane: X[k * WAVE]
+    const VpStreamParams sp = d.pitch[q.s].sp;
+    const int order = isS ? sp.orderSynth : sp.orderVoice;
+    const double *rg = isS ? v.rS + (size_t)w * V2_RS_STRIDE : v.rV + (size_t)w * V2_RV_STRIDE;
+    double *ag = isS ? v.aS + (size_t)w * V2_RS_STRIDE : v.aV + (size_t)w * V2_RV_STRIDE;
+    if (q.live)
+        for (int k = 0; k <= order; k++) R[k * WAVE] = rg[k];
+    if (q.live) {
+        const double r0 = R[0];
+        if (fabs(r0) < g.levEps) {                                          // :110-114
+            for (int k = 0; k <= order; k++) ag[k] = (k == 0) ? 1.0 : 0.0;
+        } else {
+            A[0] = 1.0;
+            A[WAVE] = R[WAVE] / r0;
+            for (int p = 2; p < order + 1; p++) {
+                double rho_a = 0.0, r_a = 0.0;
+                int i = 1;
+                for (; i + 4 <= p; i += 4) {                                // :120-128, four terms' operands read ahead of the ordered adds
+                    double ai[4], rp[4], ri[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { ai[t] = A[(i + t) * WAVE]; rp[t] = R[(p - i - t) * WAVE]; ri[t] = R[(i + t) * WAVE]; }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { rp[t] = rp[t] * ai[t]; ri[t] = ri[t] * ai[t]; }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { rho_a += rp[t]; r_a += ri[t]; }
+                }
+                for (; i < p; i++) {
+                    const double ai = A[i * WAVE];
+                    rho_a += R[(p - i) * WAVE] * ai;
+                    r_a += R[i * WAVE] * ai;
+                }
+                const double k = (R[p * WAVE] - rho_a) / (r0 - r_a);
+                i = 1;
+                for (; 2 * (i + 3) < p; i += 4) {                           // a[i] = aPrev[i] - k aPrev[p-i], both ends of four pairs
+                    double ai[4], aj[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { ai[t] = A[(i + t) * WAVE]; aj[t] = A[(p - i - t) * WAVE]; }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { A[(i + t) * WAVE] = ai[t] - k * aj[t]; A[(p - i - t) * WAVE] = aj[t] - k * ai[t]; }
+                }
+                for (; 2 * i <= p; i++) {
+                    const double ai = A[i * WAVE], aj = A[(p - i) * WAVE];
+                    A[i * WAVE] = ai - k * aj;
+                    if (2 * i != p) A[(p - i) * WAVE] = aj - k * ai;
+                }
+                A[p * WAVE] = k;
+            }
+            ag[0] = 1.0;
+            for (int k = 1; k <= order; k++) ag[k] = A[k * WAVE] * -1.;     // :145-146
+        }
+    }
+}
+
+// levinson, register-resident: the same recursion fully unrolled for orders up to P, coefficient and autocorrelation vectors
+// in registers (no LDS round trips in the two ordered sums: the LDS form above spends its time waiting for them).  A lane whose
+// own order is smaller steps out of the remaining order steps (EXEC mask).  Orders above V2_ORDER_MAX take the LDS form.
+template <int P>
+__global__ __launch_bounds__(64) void vp_k_v2_levinson_reg(VpGeom g, VpCall c, VpDev d, VpV2 v, int isS)
+{
+    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const VpStreamParams sp = d.pitch[q.s].sp;
+    const int order = isS ? sp.orderSynth : sp.orderVoice;
+    const int wc = q.b * c.nWin + q.j;
+    const double *rg = isS ? v.rS + (size_t)wc * V2_RS_STRIDE : v.rV + (size_t)wc * V2_RV_STRIDE;
+    double *ag = isS ? v.aS + (size_t)wc * V2_RS_STRIDE : v.aV + (size_t)wc * V2_RV_STRIDE;
+    double r[P + 1], a[P + 1];
+#pragma unroll
+    for (int k = 0; k <= P; k++) { r[k] = (k <= order) ? rg[k] : 0.0; a[k] = 0.0; }
+    if (!q.live) return;
+    const double r0 = r[0];
+    if (fabs(r0) < g.levEps) {                                              // :110-114
+        for (int k = 0; k <= order; k++) ag[k] = (k == 0) ? 1.0 : 0.0;
+        return;
+    }
+    a[0] = 1.0;
+    a[1] = r[1] / r0;
+#pragma unroll
+    for (int p = 2; p <= P; p++) {
+        if (p <= order) {
+            double rho_a = 0.0, r_a = 0.0;
+#pragma unroll
+            for (int i = 1; i < p; i++) {                                   // :120-128
+                rho_a += r[p - i] * a[i];
+                r_a += r[i] * a[i];
+            }
+            const double k = (r[p] - rho_a) / (r0 - r_a);
+#pragma unroll
+            for (int i = 1; 2 * i <= p; i++) {                              // a[i] = aPrev[i] - k aPrev[p-i], both ends of the pair
+                const double ai = a[i], aj = a[p - i];
+                a[i] = ai - k * aj;
+                if (2 * i != p) a[p - i] = aj - k * ai;
+            }
+            a[p] = k;
+        }
+    }
+    ag[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= P; k++)
+        if (k <= order) ag[k] = a[k] * -1.;                                 // :145-146
+}
+
+// ------------------------------------------------------------------------------------------------
+// fir: e[i] = a[0] xw[i] + sum_{k=1..min(order,i)} xw[i-k] a[k], xw = x * anWindow (VocoderProcess.cpp:235-251), taps in
+// the reference's order.  Lane = window, the wave takes outputs [i0, i0 + 64) of 64 windows: coefficients (P + 1, zero
+// above the lane's own order) and the last P inputs live in registers; four outputs per trip (the next trip's samples
+// requested before this trip's arithmetic), then the history moves by four.  A tap that reaches left of the window, or
+// above the order, multiplies an exact zero: the sum is unchanged.
+// isS = 0: voice -> eV, 1: side chain -> eS (a launch of its own: its orders are much smaller).
+// Also leaves the slice's own sum of e^2 (in order) in EEp: VP_IIR_FAST takes the window energies as the sum of those (the
+// reference's single left-to-right sum -- vp_k_v2_energy -- stays the exact mode's), and then eVoice is not stored at all.
+template <int P>
+__global__ __launch_bounds__(64) void vp_k_v2_fir(VpGeom g, VpCall c, VpDev d, VpV2 v, int isS)
+{
+    static_assert(P % 4 == 0 && P >= 4, "P multiple of 4");
+    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const int W = g.W, i0 = blockIdx.y * V2_FIR_SLICE, i1 = min(W, i0 + V2_FIR_SLICE);
+    const float *__restrict__ x = v.lin + ((size_t)q.b * 2 + (isS ? 1 : 0)) * v.span + (size_t)q.j * g.h;
+    const double *__restrict__ win = d.vocWin;
+    const VpStreamParams sp = d.pitch[q.s].sp;
+    const int order = isS ? sp.orderSynth : sp.orderVoice;
+    const int wc = q.b * c.nWin + q.j;
+    const double *ag = isS ? v.aS + (size_t)wc * V2_RS_STRIDE : v.aV + (size_t)wc * V2_RV_STRIDE;
+    double *e = (isS ? v.eS : v.eV) + (size_t)wc * W;
+    const bool store = q.live && (isS || !c.iirFast);
+    double a[P + 1], h[P + 4];                                              // h[q] = xw[i - 1 - q]
+#pragma unroll
+    for (int k = 0; k <= P; k++) a[k] = (k <= order) ? ag[k] : 0.0;
+#pragma unroll
+    for (int t = 0; t < P; t++) { const int idx = i0 - 1 - t; h[t] = (idx >= 0) ? (double)x[idx] * win[idx] : 0.0; }
+    double Ep = 0.0;
+    const int i4 = i0 + ((i1 - i0) & ~3);
+    float f0[4], f1[4];
+#define V2_FIR_LOAD(F, I) _Pragma("unroll") for (int t = 0; t < 4; t++) F[t] = x[(I) + t];
+#define V2_FIR_TRIP(F, I) { double xn[4], en[4]; \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) xn[t] = (double)F[t] * win[(I) + t]; \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) { \
+            /* tap k of output i + t reads xw[i + t - k]: one of this trip's new inputs (k <= t) or history h[k - 1 - t] */ \
+            double acc = a[0] * xn[t]; \
+            _Pragma("unroll") for (int k = 1; k <= P; k++) { \
+                const double xv_ = (k <= t) ? xn[t - k < 0 ? 0 : t - k] : h[k - 1 - t < 0 ? 0 : k - 1 - t]; \
+                acc += xv_ * a[k]; } \
+            en[t] = acc; } \
+        _Pragma("unroll") for (int t = P - 1; t >= 4; t--) h[t] = h[t - 4]; \
+        h[3] = xn[0]; h[2] = xn[1]; h[1] = xn[2]; h[0] = xn[3]; \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) Ep += en[t] * en[t]; \
+        if (store) { e[(I)] = en[0]; e[(I) + 1] = en[1]; e[(I) + 2] = en[2]; e[(I) + 3] = en[3]; } }
+    if (i4 > i0) { V2_FIR_LOAD(f0, i0) }
+    int i = i0;
+    for (; i < i4; i += 8) {
+        const bool more1 = i + 4 < i4;
+        if (more1) { V2_FIR_LOAD(f1, i + 4) }
+        V2_FIR_TRIP(f0, i)
+        if (more1) {
+            if (i + 8 < i4) { V2_FIR_LOAD(f0, i + 8) }
+            V2_FIR_TRIP(f1, i + 4)
+        }
+    }
+#undef V2_FIR_LOAD
+#undef V2_FIR_TRIP
+    for (i = i4; i < i1; i++) {                                             // window lengths that are not a multiple of 4
+        const double xn = (double)x[i] * win[i];
+        double acc = a[0] * xn;
+#pragma unroll
+        for (int k = 1; k <= P; k++) acc += h[k - 1] * a[k];
+#pragma unroll
+        for (int t = P - 1; t >= 1; t--) h[t] = h[t - 1];
+        h[0] = xn;
+        Ep += acc * acc;
+        if (store) e[i] = acc;
+    }
+    if (q.live) v.EEp[((size_t)wc * 2 + (isS ? 1 : 0)) * v.nSlices + blockIdx.y] = Ep;
+}
+
+// VP_IIR_FAST: window energies as the in-order sum of the slices' sums
+__global__ __launch_bounds__(64) void vp_k_v2_energy_slices(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    const int w = blockIdx.x * WAVE + threadIdx.x;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!q.live) return;
+    const int nS = (g.W + V2_FIR_SLICE - 1) / V2_FIR_SLICE;
+    for (int which = 0; which < 2; which++) {
+        const double *pp = v.EEp + ((size_t)w * 2 + which) * v.nSlices;
+        double E = 0.0;
+        for (int k = 0; k < nS; k++) E += pp[k];
+        v.EE[(size_t)w * 2 + which] = E;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// energy: E = sum e[i]^2 left to right (VocoderProcess.cpp:250), lane = window, blockIdx.y = 0: eVoice, 1: eSynth.
+// Eight entries per trip, the next trip's requested before this trip's squares and ordered adds.  -> EE[w][2]
+__global__ __launch_bounds__(64) void vp_k_v2_energy(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const int W = g.W, wc = q.b * c.nWin + q.j;
+    const double *e = (blockIdx.y ? v.eS : v.eV) + (size_t)wc * W;
+    double E = 0.0;
+    const int W8 = W & ~7;
+    double a0[8], a1[8];
+#define V2_EN_LOAD(A, I) _Pragma("unroll") for (int t = 0; t < 8; t++) A[t] = e[(I) + t];
+#define V2_EN_TRIP(A) { _Pragma("unroll") for (int t = 0; t < 8; t++) A[t] = A[t] * A[t]; _Pragma("unroll") for (int t = 0; t < 8; t++) E += A[t]; }
+    if (W8 > 0) { V2_EN_LOAD(a0, 0) }
+    for (int i = 0; i < W8; i += 16) {
+        const bool more1 = i + 8 < W8;
+        if (more1) { V2_EN_LOAD(a1, i + 8) }
+        V2_EN_TRIP(a0)
+        if (more1) {
+            if (i + 16 < W8) { V2_EN_LOAD(a0, i + 16) }
+            V2_EN_TRIP(a1)
+        }
+    }
+#undef V2_EN_LOAD
+#undef V2_EN_TRIP
+    for (int i = W8; i < W; i++) { const double a_ = e[i]; E += a_ * a_; }
+    if (q.live) v.EE[(size_t)w * 2 + blockIdx.y] = E;
+}
+
+// The 10-deep energy histories as they stand right after window j of the block was pushed (VocoderProcess.cpp:264-268):
+// its own energies, the block's earlier windows (newest first), then what the stream carried in (EeArr).
+// entry t of history `which` (0 voice, 1 side chain)
+__device__ __forceinline__ double v2_hist_entry(const VpDev &d, const VpV2 &v, int s, int wBase, int j, int t, int which)
+{
+    const int jj = j - t;                                                   // window of this block, or history entry -jj - 1
+    return (jj >= 0) ? v.EE[(size_t)(wBase + jj) * 2 + which] : d.EeArr[(size_t)s * 20 + which * 10 - jj - 1];
+}
+__device__ __forceinline__ void v2_histories(const VpDev &d, const VpV2 &v, int s, int wBase, int j, double hv[10], double hs[10])
+{
+#pragma unroll
+    for (int t = 0; t < 10; t++) { hv[t] = v2_hist_entry(d, v, s, wBase, j, t, 0); hs[t] = v2_hist_entry(d, v, s, wBase, j, t, 1); }
+}
+
+// g = sqrt(sum EeVoiceArr / sum EeSynthArr) if EeSynth > 1e-4 else 0 (:270-275), for window j of stream s
+__device__ __forceinline__ double v2_gain(const VpGeom &g, const VpDev &d, const VpV2 &v, int s, int wBase, int j)
+{
+    double hv[10], hs[10];
+    v2_histories(d, v, s, wBase, j, hv, hs);
+    if (!(hs[0] > g.eeFloor)) return 0.0;
+    double sv = 0.0, ss = 0.0;
+#pragma unroll
+    for (int t = 0; t < 10; t++) sv += hv[t];
+#pragma unroll
+    for (int t = 0; t < 10; t++) ss += hs[t];
+    return sqrt(sv / ss);
+}
+
+// ------------------------------------------------------------------------------------------------
+// iir, EXACT: out[i] = g e[i] - sum_{k=1..min(order,i)} out[i-k] a[k] in the reference's order (VocoderProcess.cpp:277-286),
+// lane = window: the register-resident chain of vp_k_vocoder (iir_exact_lane), now with 64 different windows in the lanes.
+template <int P>
+__global__ __launch_bounds__(64) void vp_k_v2_iir_exact(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const int W = g.W;
+    // every lane runs the chain (full EXEC): lanes past the last window redo it (identical stores), windows of gated
+    // streams chew on whatever their rows hold -- nothing reads those rows (vp_k_v2_ola looks at the gate)
+    const int wc = q.b * c.nWin + q.j;
+    const int order = d.pitch[q.s].sp.orderVoice;
+    const double *es = v.eS + (size_t)wc * W, *a = v.aV + (size_t)wc * V2_RV_STRIDE;
+    double *out = v.eV + (size_t)wc * W;
+    const double gg = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
+    iir_exact_lane<P>(es, out, W & ~3, a, order, (const double *)nullptr, gg);
+    for (int i = W & ~3; i < W; i++) {                                     // window lengths that are not a multiple of 4
+        double acc = gg * es[i];
+        const int kmax = min(order, i);
+        for (int k = 1; k <= kmax; k++) acc -= out[i - k] * a[k];
+        out[i] = acc;
+    }
+}
+
+// iir, FAST (tolerance mode): the same filter as transposed direct form II,  y = g x + s_1;  s_k = s_{k+1} - a_k y  (one fused
+// multiply-add per tap and no dependence between the taps of a sample), with a window's state spread over a 16-lane ROW:
+// lane m of the row owns taps m T + 1 .. m T + T (orders up to 16 T).  s_1 reaches every lane of the row through the DPP
+// row broadcast of v_fmac_f64, the state crosses to the lower lane through a DPP row shift; four windows per wavefront.
+// With one lane per window a sample costs order + 1 dependent-issue slots and a launch has only NW / 64 wavefronts; this
+// way it costs T + 3 and there are sixteen times as many.  Differs from the exact chain by rounding only.
+template <int T>
+__global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    const int lane = threadIdx.x, m = lane & 15;
+    const int w = blockIdx.x * 4 + (lane >> 4);
+    const V2Win q = v2_window(c, d, v, w);
+    if (!__any(q.live)) return;
+    const int W = g.W, wc = q.b * c.nWin + q.j;
+    const int order = d.pitch[q.s].sp.orderVoice;
+    const double *es = v.eS + (size_t)wc * W, *ag = v.aV + (size_t)wc * V2_RV_STRIDE;
+    double *out = v.eV + (size_t)wc * W;
+    const double gg = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
+    const bool store = q.live && m == 0;
+    const double one = 1.0;
+    double na[T], st[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) { const int k = m * T + 1 + j; na[j] = (k <= order) ? -ag[k] : 0.0; st[j] = 0.0; }
+    const int W8 = W & ~7;
+    double x0[8], x1[8];
+#define V2_IF_LOAD(X, I) _Pragma("unroll") for (int t = 0; t < 8; t++) X[t] = es[(I) + t];
+#define V2_IF_STEP(XV, YV) { \
+        double yy = gg * (XV); \
+        double s0 = st[0]; \
+        asm volatile("s_nop 1" : "+v"(s0), "+v"(yy));                       /* VALU write -> DPP read */ \
+        VP_FMAC_BCAST(yy, s0, one, 0);                                      /* + s_1, held by lane 0 of the row */ \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s0), 0x101, 0xf, 0xf, false);    /* row_shl:1: lane m <- lane m + 1, */ \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s0), 0x101, 0xf, 0xf, false);    /* 0 into the row's last lane      */ \
+        const double in_ = __hiloint2double(hi_, lo_); \
+        _Pragma("unroll") for (int j = 0; j + 1 < T; j++) st[j] = __builtin_fma(na[j], yy, st[j + 1]); \
+        st[T - 1] = __builtin_fma(na[T - 1], yy, in_); \
+        YV = yy; }
+#define V2_IF_TRIP(X, I) { double y_[8]; \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) V2_IF_STEP(X[t], y_[t]) \
+        if (store) { _Pragma("unroll") for (int t = 0; t < 8; t++) out[(I) + t] = y_[t]; } }
+    if (W8 > 0) { V2_IF_LOAD(x0, 0) }
+    for (int i = 0; i < W8; i += 16) {
+        const bool more1 = i + 8 < W8;
+        if (more1) { V2_IF_LOAD(x1, i + 8) }
+        V2_IF_TRIP(x0, i)
+        if (more1) {
+            if (i + 16 < W8) { V2_IF_LOAD(x0, i + 16) }
+            V2_IF_TRIP(x1, i + 8)
+        }
+    }
+    for (int i = W8; i < W; i++) {
+        double yv;
+        V2_IF_STEP(es[i], yv)
+        if (store) out[i] = yv;
+    }
+#undef V2_IF_LOAD
+#undef V2_IF_STEP
+#undef V2_IF_TRIP
+}
+
+// ------------------------------------------------------------------------------------------------
+// ola: every output sample adds its covering windows in window order -- the order of the reference's addOutSample calls
+// (VocoderProcess.cpp:291-295, MyBuffer.cpp:181-191) -- each term gainVoc * out[i] * stWindow[i]; optionally the emit
+// epilogue.  Workgroup = stream.
+__global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, VpV2 v, float *__restrict__ out)
+{
+    const int s = vp_stream(d), b = blockIdx.x, tid = threadIdx.x;
+    if (d.gate[s * 2 + 0] && d.gate[s * 2 + 1]) {
+        if (tid < 20) {                                                      // the block's last window leaves the histories behind
+            // (twenty lanes of ONE wavefront: all of them have read the old entries before any of them stores)
+            const double hnew = v2_hist_entry(d, v, s, b * c.nWin, c.nWin - 1, tid % 10, tid / 10);
+            d.EeArr[(size_t)s * 20 + tid] = hnew;
+        }
+        const double gainVoc = d.pitch[s].sp.gainVoc;
+        const double *o = v.eV + (size_t)b * c.nWin * g.W;
+        double *acc = d.outAcc + (size_t)s * g.outSize;
+        const int W = g.W, span = (c.nWin - 1) * g.h + W;
+        for (int t = tid; t < span; t += blockDim.x) {
+            int pos = (c.outCounter + c.vStart + t) % g.outSize;
+            double a = acc[pos];
+            const int jlo = max(0, (t - W + g.h) / g.h), jhi = min(c.nWin - 1, t / g.h);
+            for (int j = jlo; j <= jhi; j++) {
+                const int i = t - j * g.h;
+                if (i >= 0 && i < W) a += gainVoc * o[(size_t)j * W + i] * d.vocWin[i];
+            }
+            acc[pos] = a;
+        }
+    }
+    if (c.fuseEmit) {
+        __syncthreads();
+        emit_block(g, c, d, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the pipeline (called from vp_capi.hip's process_device)
+#define V2_LAUNCH(K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, st, __VA_ARGS__)
+
+template <int P> static void v2_launch_fir_t(dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
+{
+    V2_LAUNCH(vp_k_v2_fir<P>, grid, dim3(64), 0, g, c, d, v, isS);
+}
+static void v2_launch_fir(int order, dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
+{
+    switch ((order + 7) & ~7) {
+    case 8: v2_launch_fir_t<8>(grid, st, g, c, d, v, isS); break;
+    case 16: v2_launch_fir_t<16>(grid, st, g, c, d, v, isS); break;
+    case 24: v2_launch_fir_t<24>(grid, st, g, c, d, v, isS); break;
+    case 32: v2_launch_fir_t<32>(grid, st, g, c, d, v, isS); break;
+    case 40: v2_launch_fir_t<40>(grid, st, g, c, d, v, isS); break;
+    default: v2_launch_fir_t<48>(grid, st, g, c, d, v, isS); break;
+    }
+}
+template <int P> static void v2_launch_iir_exact(dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v)
+{
+    V2_LAUNCH(vp_k_v2_iir_exact<P>, grid, dim3(64), 0, g, c, d, v);
+}
+
+int vp_v2_init()
+{
+    // dynamic-LDS ceilings of the two kernels that use it (process-wide function attributes)
+    if (hipFuncSetAttribute((const void *)vp_k_v2_levinson, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (VP_ORDER_MAX + 1) * 64 * 8) != hipSuccess) return -1;
+    return 0;
+}
+
+void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st)
+{
+    const int NW = v.nStreams * c.nWin, nGroups = (NW + 63) / 64;
+    V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
+    // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
+    if (NW * ((v.oVmax + v.oSmax + 2 + 7) / 8) >= 2048) {
+        const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
+        V2_LAUNCH(vp_k_v2_autocorr<8>, dim3(nGroups, gy), dim3(64), 0, g, c, d, v);
+    } else {
+        const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
+        V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), 0, g, c, d, v);
+    }
+    auto lev = [&](int top, int isS) {
+        switch ((top + 7) & ~7) {
+        case 8: V2_LAUNCH(vp_k_v2_levinson_reg<8>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 16: V2_LAUNCH(vp_k_v2_levinson_reg<16>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 24: V2_LAUNCH(vp_k_v2_levinson_reg<24>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 32: V2_LAUNCH(vp_k_v2_levinson_reg<32>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 40: V2_LAUNCH(vp_k_v2_levinson_reg<40>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        default: V2_LAUNCH(vp_k_v2_levinson_reg<48>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        }
+    };
+    if (getenv("VP_V2_LEV_LDS"))
+        V2_LAUNCH(vp_k_v2_levinson, dim3(nGroups, 2), dim3(64), 2 * (size_t)(std::max(v.oVmax, v.oSmax) + 1) * 64 * sizeof(double), g, c, d, v);
+    else { lev(v.oSmax, 1); lev(v.oVmax, 0); }
+    const dim3 gf(nGroups, (g.W + V2_FIR_SLICE - 1) / V2_FIR_SLICE);
+    v2_launch_fir(v.oSmax, gf, st, g, c, d, v, 1);
+    v2_launch_fir(v.oVmax, gf, st, g, c, d, v, 0);
+    if (c.iirFast) {
+        V2_LAUNCH(vp_k_v2_energy_slices, dim3(nGroups), dim3(64), 0, g, c, d, v);
+        const dim3 gi((NW + 3) / 4);
+        switch ((v.oVmax + 15) / 16) {
+        case 1: V2_LAUNCH(vp_k_v2_iir_fast<1>, gi, dim3(64), 0, g, c, d, v); break;
+        case 2: V2_LAUNCH(vp_k_v2_iir_fast<2>, gi, dim3(64), 0, g, c, d, v); break;
+        default: V2_LAUNCH(vp_k_v2_iir_fast<3>, gi, dim3(64), 0, g, c, d, v); break;
+        }
+    } else {
+        V2_LAUNCH(vp_k_v2_energy, dim3(nGroups, 2), dim3(64), 0, g, c, d, v);
+        switch ((v.oVmax + 7) & ~7) {
+        case 8: v2_launch_iir_exact<8>(dim3(nGroups), st, g, c, d, v); break;
+        case 16: v2_launch_iir_exact<16>(dim3(nGroups), st, g, c, d, v); break;
+        case 24: v2_launch_iir_exact<24>(dim3(nGroups), st, g, c, d, v); break;
+        case 32: v2_launch_iir_exact<32>(dim3(nGroups), st, g, c, d, v); break;
+        case 40: v2_launch_iir_exact<40>(dim3(nGroups), st, g, c, d, v); break;
+        default: v2_launch_iir_exact<48>(dim3(nGroups), st, g, c, d, v); break;
+        }
+    }
+    V2_LAUNCH(vp_k_v2_ola, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_out);
+}
