@@ -147,7 +147,7 @@ static int voc_lite_slots(const vp_handle *h, bool iirFast, int nw)
 #define VP_V2_MIN_WINDOWS 3072
 static bool voc_batched_for(const vp_handle *h, int nStreams, int nWin, int oV, int oS)
 {
-    if (!h->v2.lin || h->vocPath == VP_VOC_WORKGROUP || nWin < 1 || nWin > 64) return false;
+    if (!h->v2.xT || h->vocPath == VP_VOC_WORKGROUP || nWin < 1 || nWin > 64) return false;
     if (oV > V2_ORDER_MAX || oS > VP_ORDER_MAX_SYNTH || oV < 2 || oS < 2) return false;
     return h->vocPath == VP_VOC_BATCHED || (size_t)nStreams * nWin >= VP_V2_MIN_WINDOWS;
 }
@@ -556,15 +556,19 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         memset(&h->v2, 0, sizeof h->v2);
         h->nWinMax = (N + hop - 1) / hop;
         const size_t NW = (size_t)S * h->nWinMax;
-        h->v2.span = (h->nWinMax - 1) * hop + W;
-        if (h->nWinMax <= 64 && h->v2.span < g.inSize && vp_v2_init() == 0) {
-            RC(dev_alloc(h, &h->v2.lin, (size_t)S * 2 * h->v2.span + 64));      // (+ padding: the autocorrelation reads a few samples ahead)
-            RC(dev_alloc(h, &h->v2.rV, NW * V2_RV_STRIDE, false));
-            RC(dev_alloc(h, &h->v2.aV, NW * V2_RV_STRIDE, false));
-            RC(dev_alloc(h, &h->v2.rS, NW * V2_RS_STRIDE, false));
-            RC(dev_alloc(h, &h->v2.aS, NW * V2_RS_STRIDE, false));
-            RC(dev_alloc(h, &h->v2.eV, NW * W));
-            RC(dev_alloc(h, &h->v2.eS, NW * W));
+        if (h->nWinMax <= 64 && vp_v2_init() == 0) {
+            h->v2.nGroupsMax = (int)((NW + 63) / 64);
+            h->v2.W4p = (W + 3) / 4 + 8;                                  // (+ padding: the autocorrelation reads a few samples ahead)
+            h->v2.W2p = (W + 1) / 2 + 2;
+            RC(dev_alloc(h, &h->v2.xT, (size_t)2 * h->v2.nGroupsMax * h->v2.W4p * 256));
+            RC(dev_alloc(h, &h->v2.eT, (size_t)2 * h->v2.nGroupsMax * h->v2.W2p * 128));
+            RC(dev_alloc(h, &h->v2.out, NW * W));
+            const size_t NWp = (size_t)h->v2.nGroupsMax * 64;
+            RC(dev_alloc(h, &h->v2.rV, NWp * V2_RV_STRIDE));
+            RC(dev_alloc(h, &h->v2.aV, NWp * V2_RV_STRIDE));
+            RC(dev_alloc(h, &h->v2.rS, NWp * V2_RS_STRIDE));
+            RC(dev_alloc(h, &h->v2.aS, NWp * V2_RS_STRIDE));
+            RC(dev_alloc(h, &h->v2.meta, NWp));
             RC(dev_alloc(h, &h->v2.EE, NW * 2));
             h->v2.nSlices = (W + V2_FIR_SLICE - 1) / V2_FIR_SLICE;
             RC(dev_alloc(h, &h->v2.EEp, NW * 2 * h->v2.nSlices));

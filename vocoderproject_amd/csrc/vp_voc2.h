@@ -11,15 +11,17 @@
 
 // scratch of the pipeline, per handle.  NW = streams x windows per block; window w = (cohort-local stream) x nWin + j.
 struct VpV2 {
-    float *lin;                 // [S][2][span]   the block's samples per stream, linear: voice, side-chain channel 0
-    double *rV, *rS;            // [NW][V2_RV_STRIDE], [NW][V2_RS_STRIDE]   autocorrelations
+    float *xT;                  // [2][nGroupsMax][W4p][64][4]  the windows' samples, transposed tiles (see vp_voc2.hip)
+    double *rV, *rS;            // [nGroupsMax][V2_RV_STRIDE][64], [nGroupsMax][V2_RS_STRIDE][64]   autocorrelations (lag-major tiles)
     double *aV, *aS;            // same shapes: A(z) coefficients
-    double *eV, *eS;            // [NW][W] residuals; eV is overwritten by the all-pole output
+    int4 *meta;                 // [NW] per window: gate open, lpcVoice, lpcSynth, stream
+    double *eT;                 // [2][nGroupsMax][W2p][64][2]  residuals (voice, side chain), transposed tiles
+    double *out;                // [NW][W] the all-pole output, window-major
+    int nGroupsMax, W4p, W2p;   // 64-window groups the scratch holds; float4 / double2 rows per window (padded)
     double *EE;                 // [NW][2] residual energies (voice, side chain)
     double *EEp;                // [NW][2][nSlices] the same per 64-output slice of the residual kernel
     int nSlices;
     int nStreams;               // streams of this launch (the cohort)
-    int span;                   // floats per channel in lin
     int oVmax, oSmax;           // largest lpcVoice / lpcSynth over the streams (the orders themselves are per stream)
 };
 

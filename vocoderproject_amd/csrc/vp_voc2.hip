@@ -30,35 +30,81 @@
 
 // ------------------------------------------------------------------------------------------------
 // window w of the launch -> (cohort-local stream b, window j of the block), stream id, gate
-struct V2Win { int b, j, s; bool live; };
+// (one 16-byte record per window, written by the stage kernel: a lane learns everything about its window in ONE round
+// trip instead of the chain stream map -> gate -> parameters)
+struct V2Win { int b, j, s, oV, oS; bool live; };
 __device__ __forceinline__ V2Win v2_window(const VpCall &c, const VpDev &d, const VpV2 &v, int w)
 {
     V2Win q;
     const int NW = v.nStreams * c.nWin;
     const int wc = min(w, NW - 1);
+    const int4 m = v.meta[wc];
     q.b = wc / c.nWin;
     q.j = wc - q.b * c.nWin;
-    q.s = d.streamMap ? d.streamMap[q.b] : q.b;
-    q.live = w < NW && d.gate[q.s * 2 + 0] && d.gate[q.s * 2 + 1];       // VocoderProcess.cpp:199-204
+    q.s = m.w; q.oV = m.y; q.oS = m.z;
+    q.live = w < NW && m.x != 0;                                          // VocoderProcess.cpp:199-204
     return q;
 }
 
+// r / a vectors of one window: column `lane` of the tile [G][k][64] (coalesced across the lanes)
+struct V2Col { double *base; __device__ __forceinline__ double &operator[](int k) const { return base[(size_t)k * 64]; } };
+__device__ __forceinline__ V2Col v2_col(double *arr, int K, int w) { V2Col r; r.base = arr + ((size_t)(w >> 6) * K) * 64 + (w & 63); return r; }
+
 // ------------------------------------------------------------------------------------------------
-// stage: the block's window span of every stream, linear (no ring wrap), voice and side-chain channel 0.
-// lin[b][ch][i] = sample at logical index vStart + i, i < (nWin - 1) h + W.
+// Layout of what the lane-per-window kernels stream: TRANSPOSED tiles, so that the 64 lanes of a wavefront -- 64 different
+// windows -- read one contiguous kilobyte per load instead of 64 separate cache lines:
+//   xT[ch][G][i / 4][lane][4]  f32   sample i of window 64 G + lane (every window materialised, overlap and all)
+//   eT[ch][G][i / 2][lane][2]  f64   residuals
+// (ch 0 voice, 1 side chain.)  The all-pole output goes to out[w][i], window-major, which is what the overlap-add reads.
+struct V2X {                                                                // samples of one window, by index
+    const float *base; int stride;                                         // base: (G, 0, lane, 0)
+    __device__ __forceinline__ float operator[](int i) const { return base[(size_t)(i >> 2) * 256 + (i & 3)]; }
+};
+__device__ __forceinline__ V2X v2_x(const VpV2 &v, int ch, int w)
+{
+    V2X r;
+    r.base = v.xT + (((size_t)ch * v.nGroupsMax + (w >> 6)) * v.W4p * 64 + (w & 63)) * 4;
+    r.stride = 0;
+    return r;
+}
+template <class T> struct V2ET {                                            // residuals of one window, by index
+    T *base;
+    __device__ __forceinline__ T &operator[](int i) const { return base[(size_t)(i >> 1) * 128 + (i & 1)]; }
+};
+__device__ __forceinline__ V2ET<double> v2_e(const VpV2 &v, int ch, int w)
+{
+    V2ET<double> r;
+    r.base = v.eT + (((size_t)ch * v.nGroupsMax + (w >> 6)) * v.W2p * 64 + (w & 63)) * 2;
+    return r;
+}
+
+// stage: every window of the block, sample by sample (ring wrap resolved here), voice and side-chain channel 0
 __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v)
 {
     const int s = vp_stream(d), b = blockIdx.x;
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
     const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
-    float *lv = v.lin + (size_t)b * 2 * v.span, *ls = lv + v.span;
-    const int n = (c.nWin - 1) * g.h + g.W;
-    int p0 = ring_pos(c.currCounter, c.vStart, g.inSize);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int p = p0 + i;
-        p -= (p >= g.inSize) ? g.inSize : 0;                              // n < inSize: one wrap at most
-        lv[i] = vr[p];
-        ls[i] = sr0[p];
+    const int W4 = (g.W + 3) >> 2;
+    if ((int)threadIdx.x < c.nWin) {
+        const VpStreamParams sp = d.pitch[s].sp;
+        v.meta[b * c.nWin + threadIdx.x] = make_int4(d.gate[s * 2 + 0] && d.gate[s * 2 + 1], sp.orderVoice, sp.orderSynth, s);
+    }
+    for (int t = threadIdx.x; t < c.nWin * W4; t += blockDim.x) {
+        const int i4 = t / c.nWin, j = t - i4 * c.nWin;                       // window fastest: the stream's windows are adjacent lanes of the tile
+        const int w = b * c.nWin + j;
+        int p = ring_pos(c.currCounter, c.vStart + j * g.h + 4 * i4, g.inSize);
+        float a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = 4 * i4 + u < g.W;
+            a4[u] = in ? vr[p] : 0.0f;
+            b4[u] = in ? sr0[p] : 0.0f;
+            p = (p + 1 == g.inSize) ? 0 : p + 1;
+        }
+        float *xv = v.xT + ((((size_t)(w >> 6)) * v.W4p + i4) * 64 + (w & 63)) * 4;
+        float *xs = xv + (size_t)v.nGroupsMax * v.W4p * 256;
+        *(float4 *)xv = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        *(float4 *)xs = make_float4(b4[0], b4[1], b4[2], b4[3]);
     }
 }
 
@@ -76,6 +122,8 @@ __global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, 
 template <int L>
 __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
+    static_assert(L == 4 || L == 8, "lag groups of 4 or 8");
+    extern __shared__ double smem[];
     const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
     const int gV = (v.oVmax + L) / L;                                     // lag groups of the voice: ceil((oVmax + 1) / L)
     const bool isS = (int)blockIdx.y >= gV;
@@ -83,8 +131,12 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
     const V2Win q = v2_window(c, d, v, w);
     if (!__any(q.live)) return;
     const int W = g.W;
-    const float *__restrict__ x = v.lin + ((size_t)q.b * 2 + (isS ? 1 : 0)) * v.span + (size_t)q.j * g.h;
-    const double *__restrict__ win = d.vocWin;
+    const V2X x = v2_x(v, isS ? 1 : 0, q.b * c.nWin + q.j);
+    // the window function in LDS (uniform reads = broadcasts).  Scalar loads would do, but they return out of order, so each
+    // one has to be waited for on its own (lgkmcnt(0)) and the loop stalls three times per trip; LDS reads pipeline.
+    lds_f64 *wl = (lds_f64 *)smem;
+    for (int i = lane; i < W + 16; i += WAVE) wl[i] = (i < W) ? d.vocWin[i] : 0.0;
+    __syncthreads();
     double sum[L];
 #pragma unroll
     for (int j = 0; j < L; j++) sum[j] = 0.0;
@@ -92,45 +144,50 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
     const int nAll = max(0, W - m0 - (L - 1));
     const int nMain = nAll & ~7;
     if (nMain > 0) {
-        double xr[L + 8];                                                   // x[n + m0 + q], q < L + 8 (the trip's eight steps)
+        // The lane's samples x[n + m0 + q] slide through a RING of sixteen registers (static names: two trips of eight steps per
+        // loop iteration, the second one half a ring further on), eight new ones per trip; those and the eight samples of
+        // tmp = x[n] w[n] are requested one trip ahead (aligned 16-byte loads, contiguous across the lanes; the last trip
+        // reads a few samples past the window: inside the tile's padding, never used).
+        double R[16];
 #pragma unroll
-        for (int t = 0; t < L; t++) xr[t] = (double)x[m0 + t];
-        // the trip's sixteen raw samples (eight for tmp = x[n] w[n], eight new ones for the sliding window) are requested one
-        // trip AHEAD: with about one wavefront per SIMD nothing else hides the memory latency
-        float fu[8], fx[8], gu[8], gx[8];
-        // (the last trip reads up to one sample past the window: inside the staged span, or its padding, and never used)
-#define V2_AC_LOAD(FU, FX, N) _Pragma("unroll") for (int t = 0; t < 8; t++) { FU[t] = x[(N) + t]; FX[t] = x[(N) + m0 + L + t]; }
-#define V2_AC_TRIP(FU, FX, N) { double u[8]; \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) { xr[L + t] = (double)FX[t]; u[t] = (double)FU[t] * win[(N) + t]; }   /* tmp, LPC.cpp:61 */ \
+        for (int t = 0; t < L; t++) R[t] = (double)x[m0 + t];
+        float4 au0, au1, ax0, ax1, bu0, bu1, bx0, bx1;
+#define V2_AC_LOAD(U0, U1, X0, X1, N) { U0 = *(const float4 *)&x.base[(size_t)((N) >> 2) * 256]; U1 = *(const float4 *)&x.base[(size_t)(((N) >> 2) + 1) * 256]; \
+        X0 = *(const float4 *)&x.base[(size_t)(((N) + m0 + L) >> 2) * 256]; X1 = *(const float4 *)&x.base[(size_t)((((N) + m0 + L) >> 2) + 1) * 256]; }
+#define V2_AC_TRIP(PH, U0, U1, X0, X1, N) { \
+        const float fx_[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w}, fu_[8] = {U0.x, U0.y, U0.z, U0.w, U1.x, U1.y, U1.z, U1.w}; \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) R[(L + t + PH) & 15] = (double)fx_[t]; \
+        double u[8]; \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * wl[(N) + t];                 /* tmp, LPC.cpp:61 */ \
         _Pragma("unroll") for (int t = 0; t < 8; t++) { \
-            _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * xr[t + j]; p = p * win[(N) + t + m0 + j]; sum[j] += p; } } \
-        _Pragma("unroll") for (int t = 0; t < L; t++) xr[t] = xr[t + 8]; }
-        V2_AC_LOAD(fu, fx, 0)
+            _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * R[(t + j + PH) & 15]; p = p * wl[(N) + t + m0 + j]; sum[j] += p; } } }
+        V2_AC_LOAD(au0, au1, ax0, ax1, 0)
         for (int n = 0; n < nMain; n += 16) {
-            const bool more1 = n + 8 < nMain;
-            if (more1) { V2_AC_LOAD(gu, gx, n + 8) }
-            V2_AC_TRIP(fu, fx, n)
-            if (more1) {
-                if (n + 16 < nMain) { V2_AC_LOAD(fu, fx, n + 16) }
-                V2_AC_TRIP(gu, gx, n + 8)
+            V2_AC_LOAD(bu0, bu1, bx0, bx1, n + 8)
+            V2_AC_TRIP(0, au0, au1, ax0, ax1, n)
+            if (n + 8 < nMain) {
+                V2_AC_LOAD(au0, au1, ax0, ax1, n + 16)
+                V2_AC_TRIP(8, bu0, bu1, bx0, bx1, n + 8)
+            } else {
+                // (an odd number of trips: keep the ring's phase for nobody -- the tail below reads memory)
             }
         }
 #undef V2_AC_LOAD
 #undef V2_AC_TRIP
     }
     for (int n = nMain; n < W - m0; n++) {                                  // the last steps: lags drop out one by one
-        const double u = (double)x[n] * win[n];
+        const double u = (double)x[n] * wl[n];
 #pragma unroll
         for (int j = 0; j < L; j++) {
             if (n < W - m0 - j) {
                 double p = u * (double)x[n + m0 + j];
-                p = p * win[n + m0 + j];
+                p = p * wl[n + m0 + j];
                 sum[j] += p;
             }
         }
     }
     if (q.live) {
-        double *r = (isS ? v.rS + (size_t)w * V2_RS_STRIDE : v.rV + (size_t)w * V2_RV_STRIDE);
+        const V2Col r = isS ? v2_col(v.rS, V2_RS_STRIDE, w) : v2_col(v.rV, V2_RV_STRIDE, w);
         const int top = isS ? VP_ORDER_MAX_SYNTH : VP_ORDER_MAX;
 #pragma unroll
         for (int j = 0; j < L; j++)
@@ -152,10 +209,10 @@ __global__ __launch_bounds__(64) void vp_k_v2_levinson(VpGeom g, VpCall c, VpDev
     if (!__any(q.live)) return;
     const int top = isS ? v.oSmax : v.oVmax;                                // wave-uniform bound of the orders in this launch
     lds_f64 *A = (lds_f64 *)smem + lane, *R = A + (size_t)(top + 1) * WAVE;  // column of this lane: X[k * WAVE]
-    const VpStreamParams sp = d.pitch[q.s].sp;
-    const int order = isS ? sp.orderSynth : sp.orderVoice;
-    const double *rg = isS ? v.rS + (size_t)w * V2_RS_STRIDE : v.rV + (size_t)w * V2_RV_STRIDE;
-    double *ag = isS ? v.aS + (size_t)w * V2_RS_STRIDE : v.aV + (size_t)w * V2_RV_STRIDE;
+    const int order = isS ? q.oS : q.oV;
+    const int wc_ = q.b * c.nWin + q.j;
+    const V2Col rg = isS ? v2_col(v.rS, V2_RS_STRIDE, wc_) : v2_col(v.rV, V2_RV_STRIDE, wc_);
+    const V2Col ag = isS ? v2_col(v.aS, V2_RS_STRIDE, wc_) : v2_col(v.aV, V2_RV_STRIDE, wc_);
     if (q.live)
         for (int k = 0; k <= order; k++) R[k * WAVE] = rg[k];
     if (q.live) {
@@ -213,11 +270,10 @@ __global__ __launch_bounds__(64) void vp_k_v2_levinson_reg(VpGeom g, VpCall c, V
     const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
     const V2Win q = v2_window(c, d, v, w);
     if (!__any(q.live)) return;
-    const VpStreamParams sp = d.pitch[q.s].sp;
-    const int order = isS ? sp.orderSynth : sp.orderVoice;
+    const int order = isS ? q.oS : q.oV;
     const int wc = q.b * c.nWin + q.j;
-    const double *rg = isS ? v.rS + (size_t)wc * V2_RS_STRIDE : v.rV + (size_t)wc * V2_RV_STRIDE;
-    double *ag = isS ? v.aS + (size_t)wc * V2_RS_STRIDE : v.aV + (size_t)wc * V2_RV_STRIDE;
+    const V2Col rg = isS ? v2_col(v.rS, V2_RS_STRIDE, wc) : v2_col(v.rV, V2_RV_STRIDE, wc);
+    const V2Col ag = isS ? v2_col(v.aS, V2_RS_STRIDE, wc) : v2_col(v.aV, V2_RV_STRIDE, wc);
     double r[P + 1], a[P + 1];
 #pragma unroll
     for (int k = 0; k <= P; k++) { r[k] = (k <= order) ? rg[k] : 0.0; a[k] = 0.0; }
@@ -267,29 +323,37 @@ template <int P>
 __global__ __launch_bounds__(64) void vp_k_v2_fir(VpGeom g, VpCall c, VpDev d, VpV2 v, int isS)
 {
     static_assert(P % 4 == 0 && P >= 4, "P multiple of 4");
+    extern __shared__ double smem[];
     const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
     const V2Win q = v2_window(c, d, v, w);
     if (!__any(q.live)) return;
     const int W = g.W, i0 = blockIdx.y * V2_FIR_SLICE, i1 = min(W, i0 + V2_FIR_SLICE);
-    const float *__restrict__ x = v.lin + ((size_t)q.b * 2 + (isS ? 1 : 0)) * v.span + (size_t)q.j * g.h;
-    const double *__restrict__ win = d.vocWin;
-    const VpStreamParams sp = d.pitch[q.s].sp;
-    const int order = isS ? sp.orderSynth : sp.orderVoice;
+    const int order = isS ? q.oS : q.oV;
     const int wc = q.b * c.nWin + q.j;
-    const double *ag = isS ? v.aS + (size_t)wc * V2_RS_STRIDE : v.aV + (size_t)wc * V2_RV_STRIDE;
-    double *e = (isS ? v.eS : v.eV) + (size_t)wc * W;
+    const V2X x = v2_x(v, isS ? 1 : 0, wc);
+    const V2Col ag = isS ? v2_col(v.aS, V2_RS_STRIDE, wc) : v2_col(v.aV, V2_RV_STRIDE, wc);
+    const V2ET<double> e = v2_e(v, isS ? 1 : 0, wc);
     const bool store = q.live && (isS || !c.iirFast);
+    // the slice's stretch of the window function in LDS, wl[k] = win[i0 - P + k] (uniform reads: see vp_k_v2_autocorr)
+    lds_f64 *wl = (lds_f64 *)smem + P - i0;                                 // wl[i] = win[i] for i in [i0 - P, i1 + 8)
+    for (int k = lane; k < P + V2_FIR_SLICE + 8; k += WAVE) { const int i = i0 - P + k; ((lds_f64 *)smem)[k] = (i >= 0 && i < W) ? d.vocWin[i] : 0.0; }
+    __syncthreads();
     double a[P + 1], h[P + 4];                                              // h[q] = xw[i - 1 - q]
 #pragma unroll
     for (int k = 0; k <= P; k++) a[k] = (k <= order) ? ag[k] : 0.0;
 #pragma unroll
-    for (int t = 0; t < P; t++) { const int idx = i0 - 1 - t; h[t] = (idx >= 0) ? (double)x[idx] * win[idx] : 0.0; }
+    for (int t = 0; t < P; t += 4) {                                        // the P inputs in front of the slice, four per aligned load
+        const int ib = i0 - 4 - t;                                          // x[ib .. ib + 3] -> h[t + 3 .. t]
+        float4 f_ = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ib >= 0) f_ = *(const float4 *)&x.base[(size_t)(ib >> 2) * 256];
+        h[t + 3] = (double)f_.x * wl[ib]; h[t + 2] = (double)f_.y * wl[ib + 1]; h[t + 1] = (double)f_.z * wl[ib + 2]; h[t] = (double)f_.w * wl[ib + 3];
+    }
     double Ep = 0.0;
     const int i4 = i0 + ((i1 - i0) & ~3);
-    float f0[4], f1[4];
-#define V2_FIR_LOAD(F, I) _Pragma("unroll") for (int t = 0; t < 4; t++) F[t] = x[(I) + t];
+    float4 fa, fb;
+#define V2_FIR_LOAD(F, I) F = *(const float4 *)&x.base[(size_t)((I) >> 2) * 256];
 #define V2_FIR_TRIP(F, I) { double xn[4], en[4]; \
-        _Pragma("unroll") for (int t = 0; t < 4; t++) xn[t] = (double)F[t] * win[(I) + t]; \
+        xn[0] = (double)F.x * wl[(I)]; xn[1] = (double)F.y * wl[(I) + 1]; xn[2] = (double)F.z * wl[(I) + 2]; xn[3] = (double)F.w * wl[(I) + 3]; \
         _Pragma("unroll") for (int t = 0; t < 4; t++) { \
             /* tap k of output i + t reads xw[i + t - k]: one of this trip's new inputs (k <= t) or history h[k - 1 - t] */ \
             double acc = a[0] * xn[t]; \
@@ -300,22 +364,23 @@ __global__ __launch_bounds__(64) void vp_k_v2_fir(VpGeom g, VpCall c, VpDev d, V
         _Pragma("unroll") for (int t = P - 1; t >= 4; t--) h[t] = h[t - 4]; \
         h[3] = xn[0]; h[2] = xn[1]; h[1] = xn[2]; h[0] = xn[3]; \
         _Pragma("unroll") for (int t = 0; t < 4; t++) Ep += en[t] * en[t]; \
-        if (store) { e[(I)] = en[0]; e[(I) + 1] = en[1]; e[(I) + 2] = en[2]; e[(I) + 3] = en[3]; } }
-    if (i4 > i0) { V2_FIR_LOAD(f0, i0) }
+        if (store) { typedef double d2_ __attribute__((ext_vector_type(2))); d2_ p0_, p1_; p0_.x = en[0]; p0_.y = en[1]; p1_.x = en[2]; p1_.y = en[3]; \
+                     *(d2_ *)&e.base[(size_t)((I) >> 1) * 128] = p0_; *(d2_ *)&e.base[(size_t)(((I) >> 1) + 1) * 128] = p1_; } }
+    // (loads run one trip ahead and are unconditional: past the window they land in the tile's padding)
+    V2_FIR_LOAD(fa, i0)
     int i = i0;
     for (; i < i4; i += 8) {
-        const bool more1 = i + 4 < i4;
-        if (more1) { V2_FIR_LOAD(f1, i + 4) }
-        V2_FIR_TRIP(f0, i)
-        if (more1) {
-            if (i + 8 < i4) { V2_FIR_LOAD(f0, i + 8) }
-            V2_FIR_TRIP(f1, i + 4)
+        V2_FIR_LOAD(fb, i + 4)
+        V2_FIR_TRIP(fa, i)
+        if (i + 4 < i4) {
+            V2_FIR_LOAD(fa, i + 8)
+            V2_FIR_TRIP(fb, i + 4)
         }
     }
 #undef V2_FIR_LOAD
 #undef V2_FIR_TRIP
     for (i = i4; i < i1; i++) {                                             // window lengths that are not a multiple of 4
-        const double xn = (double)x[i] * win[i];
+        const double xn = (double)x[i] * wl[i];
         double acc = a[0] * xn;
 #pragma unroll
         for (int k = 1; k <= P; k++) acc += h[k - 1] * a[k];
@@ -352,7 +417,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_energy(VpGeom g, VpCall c, VpDev d
     const V2Win q = v2_window(c, d, v, w);
     if (!__any(q.live)) return;
     const int W = g.W, wc = q.b * c.nWin + q.j;
-    const double *e = (blockIdx.y ? v.eS : v.eV) + (size_t)wc * W;
+    const V2ET<double> e = v2_e(v, blockIdx.y ? 1 : 0, wc);
     double E = 0.0;
     const int W8 = W & ~7;
     double a0[8], a1[8];
@@ -415,9 +480,10 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_exact(VpGeom g, VpCall c, VpDe
     // every lane runs the chain (full EXEC): lanes past the last window redo it (identical stores), windows of gated
     // streams chew on whatever their rows hold -- nothing reads those rows (vp_k_v2_ola looks at the gate)
     const int wc = q.b * c.nWin + q.j;
-    const int order = d.pitch[q.s].sp.orderVoice;
-    const double *es = v.eS + (size_t)wc * W, *a = v.aV + (size_t)wc * V2_RV_STRIDE;
-    double *out = v.eV + (size_t)wc * W;
+    const int order = q.oV;
+    const V2ET<double> es = v2_e(v, 1, wc);
+    const V2Col a = v2_col(v.aV, V2_RV_STRIDE, wc);
+    double *out = v.out + (size_t)wc * W;
     const double gg = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
     iir_exact_lane<P>(es, out, W & ~3, a, order, (const double *)nullptr, gg);
     for (int i = W & ~3; i < W; i++) {                                     // window lengths that are not a multiple of 4
@@ -442,48 +508,52 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
     const V2Win q = v2_window(c, d, v, w);
     if (!__any(q.live)) return;
     const int W = g.W, wc = q.b * c.nWin + q.j;
-    const int order = d.pitch[q.s].sp.orderVoice;
-    const double *es = v.eS + (size_t)wc * W, *ag = v.aV + (size_t)wc * V2_RV_STRIDE;
-    double *out = v.eV + (size_t)wc * W;
+    const int order = q.oV;
+    const V2ET<double> es = v2_e(v, 1, wc);
+    const V2Col ag = v2_col(v.aV, V2_RV_STRIDE, wc);
+    double *out = v.out + (size_t)wc * W;
     const double gg = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
-    const bool store = q.live && m == 0;
-    const double one = 1.0;
+    const double one = 1.0, zero = 0.0;
     double na[T], st[T];
 #pragma unroll
     for (int j = 0; j < T; j++) { const int k = m * T + 1 + j; na[j] = (k <= order) ? -ag[k] : 0.0; st[j] = 0.0; }
-    const int W8 = W & ~7;
-    double x0[8], x1[8];
-#define V2_IF_LOAD(X, I) _Pragma("unroll") for (int t = 0; t < 8; t++) X[t] = es[(I) + t];
-#define V2_IF_STEP(XV, YV) { \
-        double yy = gg * (XV); \
+    // Sixteen samples per trip: lane m of the row loads sample i + m (ONE load per trip, requested a trip ahead), the row
+    // broadcast hands sample t to every lane, lane t keeps output t, one store per trip.
+#define V2_IF_STEP(X, U, YOUT) { \
+        double yy = zero * zero;                                            /* +0.0 in a fresh register */ \
         double s0 = st[0]; \
         asm volatile("s_nop 1" : "+v"(s0), "+v"(yy));                       /* VALU write -> DPP read */ \
+        VP_FMAC_BCAST(yy, X, gg, U);                                        /* g x[i + U] */ \
         VP_FMAC_BCAST(yy, s0, one, 0);                                      /* + s_1, held by lane 0 of the row */ \
         const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s0), 0x101, 0xf, 0xf, false);    /* row_shl:1: lane m <- lane m + 1, */ \
         const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s0), 0x101, 0xf, 0xf, false);    /* 0 into the row's last lane      */ \
         const double in_ = __hiloint2double(hi_, lo_); \
         _Pragma("unroll") for (int j = 0; j + 1 < T; j++) st[j] = __builtin_fma(na[j], yy, st[j + 1]); \
         st[T - 1] = __builtin_fma(na[T - 1], yy, in_); \
-        YV = yy; }
-#define V2_IF_TRIP(X, I) { double y_[8]; \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) V2_IF_STEP(X[t], y_[t]) \
-        if (store) { _Pragma("unroll") for (int t = 0; t < 8; t++) out[(I) + t] = y_[t]; } }
-    if (W8 > 0) { V2_IF_LOAD(x0, 0) }
-    for (int i = 0; i < W8; i += 16) {
-        const bool more1 = i + 8 < W8;
-        if (more1) { V2_IF_LOAD(x1, i + 8) }
-        V2_IF_TRIP(x0, i)
-        if (more1) {
-            if (i + 16 < W8) { V2_IF_LOAD(x0, i + 16) }
-            V2_IF_TRIP(x1, i + 8)
+        if (m == (U)) YOUT = yy; }
+#define V2_IF_TRIP(X, I) { double yo_ = 0.0; \
+        V2_IF_STEP(X, 0, yo_) V2_IF_STEP(X, 1, yo_) V2_IF_STEP(X, 2, yo_) V2_IF_STEP(X, 3, yo_) V2_IF_STEP(X, 4, yo_) V2_IF_STEP(X, 5, yo_) \
+        V2_IF_STEP(X, 6, yo_) V2_IF_STEP(X, 7, yo_) V2_IF_STEP(X, 8, yo_) V2_IF_STEP(X, 9, yo_) V2_IF_STEP(X, 10, yo_) V2_IF_STEP(X, 11, yo_) \
+        V2_IF_STEP(X, 12, yo_) V2_IF_STEP(X, 13, yo_) V2_IF_STEP(X, 14, yo_) V2_IF_STEP(X, 15, yo_) \
+        if (q.live) out[(I) + m] = yo_; }
+    const int W16 = W & ~15;
+    double xa = (W16 > 0) ? es[m] : 0.0, xb = 0.0;
+    for (int i = 0; i < W16; i += 32) {
+        if (i + 16 < W16) xb = es[i + 16 + m];
+        V2_IF_TRIP(xa, i)
+        if (i + 16 < W16) {
+            if (i + 32 < W16) xa = es[i + 32 + m];
+            V2_IF_TRIP(xb, i + 16)
         }
     }
-    for (int i = W8; i < W; i++) {
-        double yv;
-        V2_IF_STEP(es[i], yv)
-        if (store) out[i] = yv;
+    if (W16 < W) {                                                          // the ragged end: same steps, masked loads and stores
+        const double xr = (W16 + m < W) ? es[W16 + m] : 0.0;
+        double yo_ = 0.0;
+        V2_IF_STEP(xr, 0, yo_) V2_IF_STEP(xr, 1, yo_) V2_IF_STEP(xr, 2, yo_) V2_IF_STEP(xr, 3, yo_) V2_IF_STEP(xr, 4, yo_) V2_IF_STEP(xr, 5, yo_)
+        V2_IF_STEP(xr, 6, yo_) V2_IF_STEP(xr, 7, yo_) V2_IF_STEP(xr, 8, yo_) V2_IF_STEP(xr, 9, yo_) V2_IF_STEP(xr, 10, yo_) V2_IF_STEP(xr, 11, yo_)
+        V2_IF_STEP(xr, 12, yo_) V2_IF_STEP(xr, 13, yo_) V2_IF_STEP(xr, 14, yo_) V2_IF_STEP(xr, 15, yo_)
+        if (q.live && W16 + m < W) out[W16 + m] = yo_;
     }
-#undef V2_IF_LOAD
 #undef V2_IF_STEP
 #undef V2_IF_TRIP
 }
@@ -502,7 +572,7 @@ __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, 
             d.EeArr[(size_t)s * 20 + tid] = hnew;
         }
         const double gainVoc = d.pitch[s].sp.gainVoc;
-        const double *o = v.eV + (size_t)b * c.nWin * g.W;
+        const double *o = v.out + (size_t)b * c.nWin * g.W;
         double *acc = d.outAcc + (size_t)s * g.outSize;
         const int W = g.W, span = (c.nWin - 1) * g.h + W;
         for (int t = tid; t < span; t += blockDim.x) {
@@ -528,7 +598,7 @@ __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, 
 
 template <int P> static void v2_launch_fir_t(dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
-    V2_LAUNCH(vp_k_v2_fir<P>, grid, dim3(64), 0, g, c, d, v, isS);
+    V2_LAUNCH(vp_k_v2_fir<P>, grid, dim3(64), (size_t)(P + V2_FIR_SLICE + 8) * 8, g, c, d, v, isS);
 }
 static void v2_launch_fir(int order, dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
@@ -558,12 +628,12 @@ void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &
     const int NW = v.nStreams * c.nWin, nGroups = (NW + 63) / 64;
     V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
     // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
-    if (NW * ((v.oVmax + v.oSmax + 2 + 7) / 8) >= 2048) {
+    if (nGroups * ((v.oVmax + 8) / 8 + (v.oSmax + 8) / 8) >= 1024) {
         const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
-        V2_LAUNCH(vp_k_v2_autocorr<8>, dim3(nGroups, gy), dim3(64), 0, g, c, d, v);
+        V2_LAUNCH(vp_k_v2_autocorr<8>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
     } else {
         const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
-        V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), 0, g, c, d, v);
+        V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
     }
     auto lev = [&](int top, int isS) {
         switch ((top + 7) & ~7) {
