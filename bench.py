@@ -208,7 +208,7 @@ def main():
                          "(double-buffered, RCCL point-to-point).  On by default when N > 1.")
     ap.add_argument("--voc-path", default="auto", choices=["auto", "workgroup", "batched"],
                     help="vocoder implementation (vp_set_vocoder_path): one workgroup per stream, or the lane-per-window pipeline "
-                         "(auto: the pipeline from 3072 windows per block on)")
+                         "(auto: the pipeline above 256 streams)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()

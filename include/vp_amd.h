@@ -153,12 +153,20 @@ int vp_get_iir_mode(const vp_handle *h);
  * VP_VOC_WORKGROUP: one workgroup per stream, one wavefront per window (vp_k_vocoder / vp_k_vocoder_lite);
  * VP_VOC_BATCHED: a pipeline of small kernels in which one LANE owns one window (vp_voc2.hip) -- pays when a block of the
  *   batch has thousands of windows; LPC orders up to 48, at most 64 windows per stream and block, else the call falls back;
- * VP_VOC_AUTO (default): batched from 3072 windows per block on. */
+ * VP_VOC_AUTO (default): batched for batches of more than 256 streams (one workgroup per CU no longer holds them) with at
+ *   least 1024 windows per block. */
 #define VP_VOC_AUTO 0
 #define VP_VOC_WORKGROUP 1
 #define VP_VOC_BATCHED 2
 int vp_set_vocoder_path(vp_handle *h, int path);
 int vp_get_vocoder_path(const vp_handle *h);
+
+/* VP_IIR_FAST only, both processes on, batched vocoder: run the pitch corrector BESIDE the vocoder pipeline (second HIP stream,
+ * accumulator of its own, merged at emit) instead of behind it.  On by default.  The only thing given up is the order in which
+ * the two processes' contributions are added into the output accumulator (PluginProcessor.cpp:214-221), i.e. rounding; the
+ * exact mode never does this.  A caller's hip_stream is respected: the work it sees is ordered on that stream. */
+int vp_set_overlap(vp_handle *h, int on);
+int vp_get_overlap(const vp_handle *h);
 
 /* How the YIN difference function (PitchProcess.cpp:350-403) and the pitch frame's LPC autocorrelation
  * (LPC.cpp:44-97) are evaluated.

@@ -1070,6 +1070,7 @@ def test_register_light_vocoder_for_large_batches(params, N):
     def run(xs):
         p = BatchVocoderProcessor(**params)
         p.prepareToPlay(FS, N, xs.shape[0])
+        p.set_vocoder_path("workgroup")                               # (the default above 256 streams is the lane-per-window pipeline)
         assert p.vocoder_kernel_name() == "vp_k_vocoder"              # exact IIR: always the regular build
         p.set_iir_mode("fast")
         assert p.vocoder_kernel_name() == ("vp_k_vocoder_lite" if xs.shape[0] > 256 else "vp_k_vocoder")
@@ -1085,8 +1086,9 @@ def test_register_light_vocoder_for_large_batches(params, N):
     assert np.abs(ref).max() > 0.02
 
 
-@pytest.mark.parametrize("S,iir", [(1024, "exact"), (1024, "fast"), (4096, "fast")])
-def test_config3_scale_batches(S, iir):
+@pytest.mark.parametrize("S,iir,voc", [(1024, "exact", "workgroup"), (1024, "fast", "workgroup"), (4096, "fast", "workgroup"),
+                                       (1024, "exact", "auto"), (1024, "fast", "auto"), (4096, "fast", "auto")])
+def test_config3_scale_batches(S, iir, voc):
     """BASELINE configs[3] per GPU (1024 streams, pitch corrector + vocoder) and four times that: sampled streams against
     the oracle (bit-exact in exact mode, within tolerance in FAST mode, where the large-batch builds of both kernels
     run), and a size-independent property at full size: permuting the streams of the batch permutes the output."""
@@ -1100,7 +1102,10 @@ def test_config3_scale_batches(S, iir):
         p = BatchVocoderProcessor()
         p.prepareToPlay(FS, N, xs.shape[0])
         p.set_iir_mode(iir)
-        if iir == "fast":
+        p.set_vocoder_path(voc)                  # "workgroup": the large-batch builds of vp_k_vocoder; "auto": the lane-per-window pipeline here
+        if voc == "auto":
+            assert p.vocoder_kernel_name() == "vp_k_v2_pipeline"
+        elif iir == "fast":
             assert p.vocoder_kernel_name() == "vp_k_vocoder_lite" and p.pitch_kernel_name().startswith("vp_k_pitch_lite")
         return p.run(xs)
 

@@ -42,6 +42,12 @@ struct vp_handle {
     // the batched lane-per-window vocoder pipeline (vp_voc2.hip): scratch, the orders it must cover, and who picks it
     VpV2 v2;
     int vocPath = VP_VOC_AUTO, oVmax = 0, oSmax = 0, nWinMax = 0;
+    // VP_IIR_FAST, both processes on, batched vocoder: the pitch kernel runs beside the vocoder pipeline on auxStream and adds
+    // into its own accumulator (acc2), which emit merges.  acc2Live: blocks for which acc2 may still hold something.
+    hipStream_t auxStream = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    double *acc2 = nullptr;
+    int overlap = 1, acc2Live = 0;
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
@@ -142,14 +148,17 @@ static int voc_lite_slots(const vp_handle *h, bool iirFast, int nw)
     return vp_voc_lds_bytes(h->g.W, nl) <= (size_t)(80 * 1024 - 512) ? nl : 0;
 }
 
-// The batched pipeline pays when the launch has thousands of windows (a lane each); it covers LPC orders up to
-// V2_ORDER_MAX and blocks of up to 64 windows per stream.  VP_VOC_BATCHED forces it wherever it is able to run.
-#define VP_V2_MIN_WINDOWS 3072
+// The batched pipeline pays as soon as the batch no longer fits one workgroup per CU (measured, vocoder alone, default
+// geometry: 256 streams 110 us workgroup / 133 us batched; 320 streams 198 / 137; 512: 203 / 142; 1024: 389 / 184) and the
+// launch has a thousand windows or more (a lane each); it covers LPC orders up to V2_ORDER_MAX and blocks of up to 64
+// windows per stream.  VP_VOC_BATCHED forces it wherever it is able to run.
+#define VP_V2_MIN_STREAMS 257
+#define VP_V2_MIN_WINDOWS 1024
 static bool voc_batched_for(const vp_handle *h, int nStreams, int nWin, int oV, int oS)
 {
     if (!h->v2.xT || h->vocPath == VP_VOC_WORKGROUP || nWin < 1 || nWin > 64) return false;
     if (oV > V2_ORDER_MAX || oS > VP_ORDER_MAX_SYNTH || oV < 2 || oS < 2) return false;
-    return h->vocPath == VP_VOC_BATCHED || (size_t)nStreams * nWin >= VP_V2_MIN_WINDOWS;
+    return h->vocPath == VP_VOC_BATCHED || (nStreams >= VP_V2_MIN_STREAMS && (size_t)nStreams * nWin >= VP_V2_MIN_WINDOWS);
 }
 static bool voc_batched(const vp_handle *h, int nStreams, int nWin) { return voc_batched_for(h, nStreams, nWin, h->oVmax, h->oSmax); }
 
@@ -160,6 +169,13 @@ extern "C" int vp_set_vocoder_path(vp_handle *h, int path)
     return VP_OK;
 }
 extern "C" int vp_get_vocoder_path(const vp_handle *h) { return h ? h->vocPath : VP_ERR_INVALID_ARG; }
+extern "C" int vp_set_overlap(vp_handle *h, int on)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    h->overlap = on ? 1 : 0;
+    return VP_OK;
+}
+extern "C" int vp_get_overlap(const vp_handle *h) { return h ? h->overlap : VP_ERR_INVALID_ARG; }
 
 extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
 {
@@ -207,7 +223,10 @@ extern "C" int vp_create(int device, vp_handle **out)
     vp_default_params(&h->params);
     memset(&h->g, 0, sizeof h->g);
     memset(&h->d, 0, sizeof h->d);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->auxStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return VP_ERR_NO_DEVICE;
     }
@@ -219,7 +238,7 @@ static void free_all(vp_handle *h)
 {
     for (void *p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
-    h->stageIn = h->stageOut = nullptr; h->dMapAll = nullptr; h->cohorts.clear();
+    h->stageIn = h->stageOut = nullptr; h->dMapAll = nullptr; h->cohorts.clear(); h->acc2 = nullptr;
     if (h->stageInB) (void)hipFree(h->stageInB);
     if (h->stageOutB) (void)hipFree(h->stageOutB);
     h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
@@ -235,6 +254,9 @@ extern "C" int vp_destroy(vp_handle *h)
     for (auto &p : h->pending) { h->evPool.push_back(p.a); h->evPool.push_back(p.b); }
     for (hipEvent_t e : h->evPool) (void)hipEventDestroy(e);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+    if (h->auxStream) (void)hipStreamDestroy(h->auxStream);
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     delete h;
     return VP_OK;
 }
@@ -526,6 +548,8 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.voiceRing, (size_t)S * g.inSize));
     RC(dev_alloc(h, &d.synthRing, (size_t)S * 2 * g.inSize));
     RC(dev_alloc(h, &d.outAcc, (size_t)S * g.outSize));
+    RC(dev_alloc(h, &h->acc2, (size_t)S * g.outSize));
+    h->acc2Live = 0;
     RC(dev_alloc(h, &d.gate, (size_t)S * 2));
     RC(dev_alloc(h, &d.pitch, (size_t)S));
     RC(dev_alloc(h, &d.eFrame, (size_t)S * g.eLen));
@@ -741,6 +765,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
         VpCall c = c0;
         VpDev d = h->d;
         d.streamMap = co.dMap;                                               // nullptr: workgroup b serves stream b
+        d.outAcc2 = h->acc2Live > 0 ? h->acc2 : nullptr;                     // emit merges the second accumulator while it may hold anything
         c.pitchOn = co.pitchOn; c.vocOn = co.vocOn;
         // VocoderProcess::process (VocoderProcess.cpp:173-183): windows while startSample < N
         c.vStart = co.vStart;
@@ -756,11 +781,45 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
         // A launch that carries several blocks (pitch-only plan, process_blocks_device) runs the pitch kernel even when
         // its FIRST block has no chunk step to do (N smaller than the chunk): later blocks of the launch do.
         const bool runVoc = c.nWin > 0, runPitch = c.nSteps > 0 || (nBlocks > 1 && c.pitchOn);
+        bool runPitchDone = false;
         if (!runVoc && !runPitch) {
             { ProfScope ps(h, st, 0); hipLaunchKernelGGL(vp_k_ingest_gate, dim3(co.n), dim3(256), 0, st, g, c, d, d_in); }
             { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, d, d_out); }
         } else {
-            if (runVoc && voc_batched(h, co.n, c.nWin)) {
+            if (runVoc && runPitch && c.iirFast && h->overlap && nBlocks == 1 && voc_batched(h, co.n, c.nWin)) {
+                // VP_IIR_FAST (tolerance mode), both processes, batched vocoder: the pitch kernel starts on a second HIP stream
+                // as soon as the input is in the rings and the gate is known, and adds into an accumulator of its own; the
+                // vocoder pipeline's serial stages occupy few SIMDs, the pitch kernel's serial phases leave issue slots free.
+                // What is given up is the ORDER of the additions into the output accumulator (windows, then chunks, per
+                // block: PluginProcessor.cpp:214-221) -- rounding-level; VP_IIR_EXACT keeps the sequential plan below.
+                struct Fork { vp_handle *h; hipStream_t st; VpGeom g; VpCall cp; VpDev dp; const float *in; float *out; int n; hipError_t err; } fk;
+                fk.h = h; fk.st = st; fk.g = g; fk.cp = c; fk.dp = d; fk.in = d_in; fk.out = d_out; fk.n = co.n; fk.err = hipSuccess;
+                fk.cp.fuseIngest = 0; fk.cp.fuseEmit = 0; fk.cp.nBlocks = 1;
+                fk.dp.outAcc = h->acc2; fk.dp.outAcc2 = nullptr;
+                auto fork = [](void *a) {
+                    Fork *f = (Fork *)a;
+                    vp_handle *h = f->h;
+                    if ((f->err = hipEventRecord(h->evFork, f->st)) != hipSuccess) return;
+                    if ((f->err = hipStreamWaitEvent(h->auxStream, h->evFork, 0)) != hipSuccess) return;
+                    ProfScope ps(h, h->auxStream, 2);
+                    const PitchPlan plan = pitch_plan(h, true, f->cp.yinFft != 0, 1);
+                    f->cp.ldsBytes = (int)plan.lds;
+                    hipLaunchKernelGGL(plan.fn, dim3(f->n), dim3(512), plan.lds, h->auxStream, f->g, f->cp, f->dp, f->in, f->out);
+                };
+                VpCall cv = c;
+                cv.fuseIngest = 1; cv.fuseEmit = 0;
+                VpV2 v = h->v2;
+                v.nStreams = co.n; v.oVmax = h->oVmax; v.oSmax = h->oSmax;
+                { ProfScope ps(h, st, 1); vp_v2_launch(g, cv, d, v, d_in, d_out, st, fork, &fk); }
+                if (fk.err != hipSuccess) return fail_hip(h, fk.err, "fork of the pitch kernel");
+                HIPCHK(h, hipEventRecord(h->evJoin, h->auxStream));
+                HIPCHK(h, hipStreamWaitEvent(st, h->evJoin, 0));
+                VpDev de = d;
+                de.outAcc2 = h->acc2;
+                { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, de, d_out); }
+                h->acc2Live = (g.outSize + g.N - 1) / g.N + 1;               // (+1: this block's own decrement below)
+                runPitchDone = true;
+            } else if (runVoc && voc_batched(h, co.n, c.nWin)) {
                 // large batches: the pipeline of lane-per-window kernels (vp_voc2.hip), ingest+gate in front, emit behind
                 VpCall cv = c;
                 cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
@@ -784,7 +843,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
                 hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : vp_k_vocoder, dim3(co.n), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, d, d_in, d_out);
             }
-            if (runPitch) {
+            if (runPitch && !runPitchDone) {
                 VpCall cp = c;
                 cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
                 cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
@@ -815,6 +874,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             }
         }
     }
+    h->acc2Live = std::max(0, h->acc2Live - nBlocks);
     for (int b = 0; b < nBlocks; b++) {                                      // MyBuffer.cpp:129-132
         h->outCounter = (h->outCounter + g.N) % g.outSize;
         h->inCounter = (h->inCounter + g.N) % g.inSize;

@@ -94,6 +94,9 @@ struct VpDev {
     const double *twRe, *twIm; // [M/2] exp(-2 pi i j / M)
     unsigned long long *ub;  // [5]
     unsigned long long *dbg; // [64] phase timers of the -DVP_STAMPS diagnostic build
+    double *outAcc2;         // [S][outSize] second accumulator, non-null in the emit stage while it may hold anything: in
+                             // VP_IIR_FAST mode the pitch corrector can run BESIDE the vocoder pipeline (another HIP stream) and
+                             // then adds into this one; emit merges (and clears) both
     const int *streamMap;    // launch of a cohort (streams whose pitchBool/vocBool histories differ from the others'):
                              // workgroup b serves stream streamMap[b]; nullptr (the normal case): stream b
 };

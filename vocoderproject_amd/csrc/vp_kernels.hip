@@ -27,6 +27,12 @@
 
 #define WAVE 64
 
+// Orders from VP_LEV_SCALAR_MIN to 48 take the register-resident Levinson-Durbin (levinson_scalar).  Measured on one box
+// (tools/abn.sh): order 48 (configs[4]) pitch kernel +5 %, vocoder +8 %; at order 40 the wave-distributed form is 7 % faster.
+#ifndef VP_LEV_SCALAR_MIN
+#define VP_LEV_SCALAR_MIN 41
+#endif
+
 // explicit LDS address space: keeps the compiler on ds_read/ds_write instead of flat accesses
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) float lds_f32;
@@ -387,6 +393,53 @@ __device__ __forceinline__ bool levinson_row16(RP r, AP a, int order, int aLen, 
     }
     if (m >= 1) av *= -1.;
     if (lane <= order) a[lane] = av;
+    return false;
+}
+
+// Levinson-Durbin for orders 16..P by ONE wavefront with every lane running the whole recursion (LPC.cpp:107-148 as it
+// stands), the autocorrelation and coefficient vectors in REGISTERS (fully unrolled, static names).  Sixty-four lanes doing
+// the same thing is as wasteful as it sounds, but the wave-distributed form above pays two LDS round trips per order step
+// for its ordered sums (26 us at order 40, 42 us at order 48); this one has none and takes a quarter of that.
+// r, a: LDS vectors.  Returns true when the whole vector was rewritten (the |r0| < eps branch).
+// (not inlined: the body is ~8000 instructions and the kernels call it from several places)
+template <int P>
+__device__ __noinline__ bool levinson_scalar(const lds_f64 *r, lds_f64 *a, int order_, int aLen, double eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+    if (fabs(r[0]) < eps) {                        // :110-114
+        for (int i = lane; i < aLen; i += WAVE) a[i] = (i == 0) ? 1.0 : 0.0;
+        return true;
+    }
+    double rr[P + 1], aa[P + 1];
+#pragma unroll
+    for (int k = 0; k <= P; k++) { rr[k] = (k <= order) ? r[k] : 0.0; aa[k] = 0.0; }
+    const double r0 = rr[0];
+    aa[0] = 1.0;
+    aa[1] = rr[1] / r0;
+#pragma unroll
+    for (int p = 2; p <= P; p++) {
+        if (p <= order) {                          // wave-uniform
+            double rho_a = 0.0, r_a = 0.0;
+#pragma unroll
+            for (int i = 1; i < p; i++) {          // :120-128
+                rho_a += rr[p - i] * aa[i];
+                r_a += rr[i] * aa[i];
+            }
+            const double k = (rr[p] - rho_a) / (r0 - r_a);
+#pragma unroll
+            for (int i = 1; 2 * i <= p; i++) {     // a[i] = aPrev[i] - k aPrev[p-i], both ends of the pair
+                const double ai = aa[i], aj = aa[p - i];
+                aa[i] = ai - k * aj;
+                if (2 * i != p) aa[p - i] = aj - k * ai;
+            }
+            aa[p] = k;
+        }
+    }
+    if (lane == 0) a[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= P; k++)
+        if (k <= order && lane == (k & 63)) a[k] = aa[k] * -1.;             // :145-146
     return false;
 }
 
@@ -858,11 +911,14 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
             // the window's second wavefront when it has one)
             lds_f64 *scr = (W >= 128) ? D : (lds_f64 *)nullptr;
             lds_f64 *scr2 = (W >= 256) ? D + 128 : (lds_f64 *)nullptr;
+            // orders up to 48: the register-resident recursion (every lane the whole of it) -- no LDS round trips
+            auto levV = [&](lds_f64 *sc) { if (!LITE && oV >= VP_LEV_SCALAR_MIN && oV <= 48) levinson_scalar<48>((const lds_f64 *)rV, aV, oV, VP_ORDER_MAX + 1, g.levEps);
+                                           else levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, sc); };
             if (nRoles == 1) {
-                levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, scr);
+                levV(scr);
                 levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, scr);
             } else if (role == 0)
-                levinson_wave(rV, aV, oV, VP_ORDER_MAX + 1, g.levEps, scr);
+                levV(scr);
             else
                 levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, scr2);
         }
@@ -2115,6 +2171,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         if (!levLate) {
             const int order = g.orderPitch;
             const bool z = (COMMON || order < 16) ? levinson_row16(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
+                           : (!LITE && order >= VP_LEV_SCALAR_MIN && order <= 48) ? levinson_scalar<48>((const lds_f64 *)L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps)
                                         : levinson_wave(L.r, L.aPrev, order, VP_ORDER_MAX + 1, g.levEps, L.qtab);   // qtab: rebuilt per frame later
             if (tid == nt - 1) { L.ishare[2] = z ? 1 : 0; *L.lpcFlag = xcGen; }   // (a barrier follows before the FIR waves look)
             STAMPL(27);
@@ -2167,6 +2224,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         if (!specLpc || levLate) {
             STAMPL_BEGIN();
             const bool z = (COMMON || g.orderPitch < 16) ? levinson_row16(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps)
+                           : (!LITE && g.orderPitch >= VP_LEV_SCALAR_MIN && g.orderPitch <= 48) ? levinson_scalar<48>((const lds_f64 *)L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps)
                                                : levinson_wave(L.r, L.aPrev, g.orderPitch, VP_ORDER_MAX + 1, g.levEps, L.qtab);
             if (tid == nt - 1) L.ishare[2] = z ? 1 : 0;
             __threadfence_block();
@@ -2530,6 +2588,7 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
     const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     const float *sr1 = sr0 + g.inSize;
     double *acc = d.outAcc + (size_t)s * g.outSize;
+    double *acc2 = d.outAcc2 ? d.outAcc2 + (size_t)s * g.outSize : nullptr;
     float *o = out + (size_t)s * (c.inplace ? 3 : 2) * g.N;
     // the stream's dry-path switches and gains: from the state the pitch kernel holds in LDS, else from HBM
     const int dryOn = stl ? stl->sp.dryOn : d.pitch[s].sp.dryOn, synthOn = stl ? stl->sp.synthOn : d.pitch[s].sp.synthOn;
@@ -2539,6 +2598,7 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
         int pos = (c.outCounter + boff + i) % g.outSize;
         int pin = (c.currCounter + boff + i) % g.inSize;
         double v = acc[pos];
+        if (acc2) { v += acc2[pos]; acc2[pos] = 0.0; }                       // the pitch corrector's share, when it ran beside the vocoder
         if (dryOn) v += (double)vr[pin] * gainVoice;
         double l = v, r = v;
         if (synthOn) { l += (double)sr0[pin] * gainSynth; r += (double)sr1[pin] * gainSynth; }

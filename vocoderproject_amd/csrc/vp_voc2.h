@@ -26,4 +26,6 @@ struct VpV2 {
 };
 
 int vp_v2_init();
-void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st);
+// `afterIngest` (optional) is called right behind the launch of the ingest+gate+stage kernel (what the caller wants to start beside the rest)
+void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
+                  void (*afterIngest)(void *) = nullptr, void *hookArg = nullptr);

@@ -519,11 +519,18 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
     for (int j = 0; j < T; j++) { const int k = m * T + 1 + j; na[j] = (k <= order) ? -ag[k] : 0.0; st[j] = 0.0; }
     // Sixteen samples per trip: lane m of the row loads sample i + m (ONE load per trip, requested a trip ahead), the row
     // broadcast hands sample t to every lane, lane t keeps output t, one store per trip.
-#define V2_IF_STEP(X, U, YOUT) { \
-        double yy = zero * zero;                                            /* +0.0 in a fresh register */ \
+    // (g x for the sixteen samples of a trip is taken first, off the recursion's critical path: per sample the chain is
+    // then  s_1 broadcast-add -> state update  and nothing else)
+#define V2_IF_GX(X, GX) { _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) GX[u_] = zero * zero; \
+        double xx_ = X; asm volatile("s_nop 1" : "+v"(xx_)); \
+        VP_FMAC_BCAST(GX[0], xx_, gg, 0); VP_FMAC_BCAST(GX[1], xx_, gg, 1); VP_FMAC_BCAST(GX[2], xx_, gg, 2); VP_FMAC_BCAST(GX[3], xx_, gg, 3); \
+        VP_FMAC_BCAST(GX[4], xx_, gg, 4); VP_FMAC_BCAST(GX[5], xx_, gg, 5); VP_FMAC_BCAST(GX[6], xx_, gg, 6); VP_FMAC_BCAST(GX[7], xx_, gg, 7); \
+        VP_FMAC_BCAST(GX[8], xx_, gg, 8); VP_FMAC_BCAST(GX[9], xx_, gg, 9); VP_FMAC_BCAST(GX[10], xx_, gg, 10); VP_FMAC_BCAST(GX[11], xx_, gg, 11); \
+        VP_FMAC_BCAST(GX[12], xx_, gg, 12); VP_FMAC_BCAST(GX[13], xx_, gg, 13); VP_FMAC_BCAST(GX[14], xx_, gg, 14); VP_FMAC_BCAST(GX[15], xx_, gg, 15); }
+#define V2_IF_STEP(GXU, U, YOUT) { \
+        double yy = GXU;                                                    /* g x[i + U] */ \
         double s0 = st[0]; \
         asm volatile("s_nop 1" : "+v"(s0), "+v"(yy));                       /* VALU write -> DPP read */ \
-        VP_FMAC_BCAST(yy, X, gg, U);                                        /* g x[i + U] */ \
         VP_FMAC_BCAST(yy, s0, one, 0);                                      /* + s_1, held by lane 0 of the row */ \
         const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s0), 0x101, 0xf, 0xf, false);    /* row_shl:1: lane m <- lane m + 1, */ \
         const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s0), 0x101, 0xf, 0xf, false);    /* 0 into the row's last lane      */ \
@@ -531,11 +538,11 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
         _Pragma("unroll") for (int j = 0; j + 1 < T; j++) st[j] = __builtin_fma(na[j], yy, st[j + 1]); \
         st[T - 1] = __builtin_fma(na[T - 1], yy, in_); \
         if (m == (U)) YOUT = yy; }
-#define V2_IF_TRIP(X, I) { double yo_ = 0.0; \
-        V2_IF_STEP(X, 0, yo_) V2_IF_STEP(X, 1, yo_) V2_IF_STEP(X, 2, yo_) V2_IF_STEP(X, 3, yo_) V2_IF_STEP(X, 4, yo_) V2_IF_STEP(X, 5, yo_) \
-        V2_IF_STEP(X, 6, yo_) V2_IF_STEP(X, 7, yo_) V2_IF_STEP(X, 8, yo_) V2_IF_STEP(X, 9, yo_) V2_IF_STEP(X, 10, yo_) V2_IF_STEP(X, 11, yo_) \
-        V2_IF_STEP(X, 12, yo_) V2_IF_STEP(X, 13, yo_) V2_IF_STEP(X, 14, yo_) V2_IF_STEP(X, 15, yo_) \
-        if (q.live) out[(I) + m] = yo_; }
+#define V2_IF_STEPS(GX, YO) \
+        V2_IF_STEP(GX[0], 0, YO) V2_IF_STEP(GX[1], 1, YO) V2_IF_STEP(GX[2], 2, YO) V2_IF_STEP(GX[3], 3, YO) V2_IF_STEP(GX[4], 4, YO) V2_IF_STEP(GX[5], 5, YO) \
+        V2_IF_STEP(GX[6], 6, YO) V2_IF_STEP(GX[7], 7, YO) V2_IF_STEP(GX[8], 8, YO) V2_IF_STEP(GX[9], 9, YO) V2_IF_STEP(GX[10], 10, YO) V2_IF_STEP(GX[11], 11, YO) \
+        V2_IF_STEP(GX[12], 12, YO) V2_IF_STEP(GX[13], 13, YO) V2_IF_STEP(GX[14], 14, YO) V2_IF_STEP(GX[15], 15, YO)
+#define V2_IF_TRIP(X, I) { double yo_ = 0.0, gx_[16]; V2_IF_GX(X, gx_) V2_IF_STEPS(gx_, yo_) if (q.live) out[(I) + m] = yo_; }
     const int W16 = W & ~15;
     double xa = (W16 > 0) ? es[m] : 0.0, xb = 0.0;
     for (int i = 0; i < W16; i += 32) {
@@ -548,12 +555,13 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
     }
     if (W16 < W) {                                                          // the ragged end: same steps, masked loads and stores
         const double xr = (W16 + m < W) ? es[W16 + m] : 0.0;
-        double yo_ = 0.0;
-        V2_IF_STEP(xr, 0, yo_) V2_IF_STEP(xr, 1, yo_) V2_IF_STEP(xr, 2, yo_) V2_IF_STEP(xr, 3, yo_) V2_IF_STEP(xr, 4, yo_) V2_IF_STEP(xr, 5, yo_)
-        V2_IF_STEP(xr, 6, yo_) V2_IF_STEP(xr, 7, yo_) V2_IF_STEP(xr, 8, yo_) V2_IF_STEP(xr, 9, yo_) V2_IF_STEP(xr, 10, yo_) V2_IF_STEP(xr, 11, yo_)
-        V2_IF_STEP(xr, 12, yo_) V2_IF_STEP(xr, 13, yo_) V2_IF_STEP(xr, 14, yo_) V2_IF_STEP(xr, 15, yo_)
+        double yo_ = 0.0, gx_[16];
+        V2_IF_GX(xr, gx_)
+        V2_IF_STEPS(gx_, yo_)
         if (q.live && W16 + m < W) out[W16 + m] = yo_;
     }
+#undef V2_IF_GX
+#undef V2_IF_STEPS
 #undef V2_IF_STEP
 #undef V2_IF_TRIP
 }
@@ -623,10 +631,12 @@ int vp_v2_init()
     return 0;
 }
 
-void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st)
+void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
+                  void (*afterIngest)(void *), void *hookArg)
 {
     const int NW = v.nStreams * c.nWin, nGroups = (NW + 63) / 64;
     V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
+    if (afterIngest) afterIngest(hookArg);
     // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
     if (nGroups * ((v.oVmax + 8) / 8 + (v.oSmax + 8) / 8) >= 1024) {
         const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;

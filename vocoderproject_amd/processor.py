@@ -99,6 +99,9 @@ def load_library():
     if hasattr(L, "vp_set_vocoder_path"):
         L.vp_set_vocoder_path.argtypes = [C.c_void_p, C.c_int]
         L.vp_get_vocoder_path.argtypes = [C.c_void_p]
+    if hasattr(L, "vp_set_overlap"):
+        L.vp_set_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.vp_get_overlap.argtypes = [C.c_void_p]
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
     L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vp_set_yin_mode.argtypes = [vp, C.c_int]
@@ -195,9 +198,13 @@ class BatchVocoderProcessor:
         self._chk(self.L.vp_set_iir_mode(self.h, {"exact": 0, "fast": 1}[mode] if isinstance(mode, str) else int(mode)))
 
     def set_vocoder_path(self, path):
-        """"auto" (default: batched from 3072 windows per block on), "workgroup" (one workgroup per stream) or
+        """"auto" (default: batched above 256 streams), "workgroup" (one workgroup per stream) or
         "batched" (the lane-per-window pipeline wherever it can run)."""
         self._chk(self.L.vp_set_vocoder_path(self.h, {"auto": 0, "workgroup": 1, "batched": 2}[path] if isinstance(path, str) else int(path)))
+
+    def set_overlap(self, on):
+        """FAST mode, both processes, batched vocoder: pitch corrector beside the vocoder pipeline (default) or behind it."""
+        self._chk(self.L.vp_set_overlap(self.h, int(bool(on))))
 
     def set_yin_mode(self, mode):
         """"direct" (default, reference summation order) or "fft" (VP_YIN_FFT accelerator)."""
