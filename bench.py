@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--voc-path", default="auto", choices=["auto", "workgroup", "batched"],
                     help="vocoder implementation (vp_set_vocoder_path): one workgroup per stream, or the lane-per-window pipeline "
                          "(auto: the pipeline above 256 streams)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="combined mode, FAST, batched vocoder: run the pitch corrector beside the vocoder pipeline instead of behind it (vp_set_overlap)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -266,6 +268,7 @@ def main():
             q.prepareToPlay(FS, N, S_)
         q.set_yin_mode(args.yin)
         q.set_vocoder_path(args.voc_path)
+        q.set_overlap(args.overlap)
         return q
 
     p = make_processor(mode, S)

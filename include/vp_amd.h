@@ -162,7 +162,8 @@ int vp_set_vocoder_path(vp_handle *h, int path);
 int vp_get_vocoder_path(const vp_handle *h);
 
 /* VP_IIR_FAST only, both processes on, batched vocoder: run the pitch corrector BESIDE the vocoder pipeline (second HIP stream,
- * accumulator of its own, merged at emit) instead of behind it.  On by default.  The only thing given up is the order in which
+ * accumulator of its own, merged at emit) instead of behind it.  OFF by default (measured: +1 % at 1024 streams, -7 % at the
+ * configs[4] geometry -- the pitch kernel's resident workgroups leave no registers for anything beside them).  What is given up is the order in which
  * the two processes' contributions are added into the output accumulator (PluginProcessor.cpp:214-221), i.e. rounding; the
  * exact mode never does this.  A caller's hip_stream is respected: the work it sees is ordered on that stream. */
 int vp_set_overlap(vp_handle *h, int on);

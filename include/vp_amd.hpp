@@ -67,7 +67,7 @@ public:
         p_ = q;
     }
     const vp_params &parameters() const { return p_; }
-    // one stream's own treeState value (after prepare; pitchBool/vocBool/lpcPitch stay per handle)
+    // one stream's own treeState value (after prepare; every parameter but lpcPitch, which is read at prepare)
     // extension: fixed interval (+-12 semitones) instead of the key's nearest note; stream = -1: all streams
     void setPitchShift(double semitones, bool on = true, int stream = -1) { check(vp_set_pitch_shift(h_, stream, on ? 1 : 0, semitones), "setPitchShift"); }
     void setStreamParameter(int stream, const char *id, float v)
@@ -81,9 +81,16 @@ public:
         else if (!std::strcmp(id, "lpcVoice")) q.lpcVoice = (int)v;
         else if (!std::strcmp(id, "lpcSynth")) q.lpcSynth = (int)v;
         else if (!std::strcmp(id, "keyPitch")) q.keyPitch = (int)v;
+        else if (!std::strcmp(id, "pitchBool")) q.pitchBool = (int)v;     // PluginProcessor.cpp:214-221: each instance has its own
+        else if (!std::strcmp(id, "vocBool")) q.vocBool = (int)v;
         else throw Error(VP_ERR_INVALID_ARG, std::string("not a per-stream parameter: ") + id);
         check(vp_set_stream_params(h_, stream, &q), id);
     }
+
+    // which implementation runs VocoderProcess::process (VP_VOC_AUTO / VP_VOC_WORKGROUP / VP_VOC_BATCHED; same results)
+    void setVocoderPath(int path) { check(vp_set_vocoder_path(h_, path), "setVocoderPath"); }
+    // VP_IIR_FAST: pitch corrector beside the vocoder pipeline instead of behind it (off by default)
+    void setOverlap(bool on) { check(vp_set_overlap(h_, on ? 1 : 0), "setOverlap"); }
 
     void prepareToPlay(double sampleRate, int samplesPerBlock, int nStreams)      // PluginProcessor.cpp:144
     {

@@ -457,6 +457,7 @@ def test_pitch_beside_vocoder_equals_pitch_behind_vocoder(S, path):
             ys.append(p.process(np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])))
         return np.concatenate(ys, axis=2), [p.pitch_state(s_) for s_ in range(min(S, U))]
 
+    assert BatchVocoderProcessor().L.vp_get_overlap(BatchVocoderProcessor().h) == 0      # off by default
     seq, st_seq = run("fast", lambda b: False)
     par, st_par = run("fast", lambda b: True)
     mix, _ = run("fast", lambda b: (b // 3) % 2 == 0)
@@ -473,3 +474,37 @@ def test_pitch_beside_vocoder_equals_pitch_behind_vocoder(S, path):
             assert np.array_equal(a[k], b_[k]), k
     ex, _ = run("exact", lambda b: True)
     _assert_equal(ex[:U], ref, "exact mode with the overlap switch on")
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_batched_vocoder_pipeline_randomised_configurations(seed):
+    """Random sample rate, host block size, orders (up to the pipeline's 48/30), gains and switches on the lane-per-window
+    pipeline (forced), a gate-crossing stream among them: bit-exact against the oracle in exact mode."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    rng = np.random.default_rng(7000 + seed)
+    fs = float(rng.choice([16000.0, 22050.0, 32000.0, 44100.0, 48000.0, 44099.0]))
+    N = int(rng.choice([64, 100, 278, 441, 512, 1000, 1024, 1536, 2048]))
+    params = dict(lpcVoice=int(rng.integers(2, 49)), lpcPitch=int(rng.integers(2, 60)), lpcSynth=int(rng.integers(2, 31)),
+                  gainPitch=float(rng.uniform(-20, 6)), gainVoc=float(rng.uniform(-20, 6)),
+                  gainVoice=float(rng.choice([-60.0, -30.0])), gainSynth=float(rng.choice([-60.0, -12.0])),
+                  pitchBool=int(rng.random() < 0.5), vocBool=1)
+    S = int(rng.integers(3, 70))
+    T = max(6, int(16000 * fs / 44100.0) // N) * N
+    x = _streams(S, T, fs=fs)
+    x[0, 0] *= np.where((np.arange(T) // 5000) % 2 == 0, 1.0, 2e-5).astype(np.float32)
+    p = BatchVocoderProcessor(**params)
+    try:
+        p.prepareToPlay(fs, N, S)
+    except VpError as e:
+        assert e.code == -4, e
+        pytest.skip("geometry exceeds the LDS budget")
+    p.set_vocoder_path("batched")
+    if p.vocoder_kernel_name() != "vp_k_v2_pipeline":
+        pytest.skip("more than 64 windows per block at this geometry: the pipeline does not take it")
+    got = p.run(x)
+    pick = sorted(set([0, 1, S // 2, S - 1]))
+    for s_ in pick:
+        o = O.OracleStream(**params)
+        o.prepare_to_play(fs, N)
+        _assert_equal(got[s_], o.run(x[s_]), f"seed {seed}: fs={fs} N={N} S={S} {params} stream {s_}")

@@ -23,7 +23,7 @@ def counter_means(d):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if not k.startswith("vp_k_"):
                 continue
             acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -37,7 +37,7 @@ def kernel_stats(d):
     res = {}
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Name"].split("(")[0]
+            k = r["Name"].split("(")[0].replace("void ", "")
             if k.startswith("vp_k_"):
                 res[k] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                           "max_us": float(r["MaxNs"]) / 1e3}

@@ -42,12 +42,14 @@ struct vp_handle {
     // the batched lane-per-window vocoder pipeline (vp_voc2.hip): scratch, the orders it must cover, and who picks it
     VpV2 v2;
     int vocPath = VP_VOC_AUTO, oVmax = 0, oSmax = 0, nWinMax = 0;
-    // VP_IIR_FAST, both processes on, batched vocoder: the pitch kernel runs beside the vocoder pipeline on auxStream and adds
-    // into its own accumulator (acc2), which emit merges.  acc2Live: blocks for which acc2 may still hold something.
+    // vp_set_overlap(h, 1), VP_IIR_FAST, both processes on, batched vocoder: the pitch kernel runs beside the vocoder pipeline on
+    // auxStream and adds into its own accumulator (acc2), which emit merges.  acc2Live: blocks for which acc2 may still hold
+    // something.  Off by default: measured 404 vs 408 us per block at 1024 streams, 880 vs 820 us at the configs[4] geometry --
+    // two resident pitch workgroups fill a CU's registers, so the two launches mostly take turns.
     hipStream_t auxStream = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     double *acc2 = nullptr;
-    int overlap = 1, acc2Live = 0;
+    int overlap = 0, acc2Live = 0;
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)

@@ -2338,7 +2338,12 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         lds_i32 *dst = (lds_i32 *)L.st;
         for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
     }
+#ifdef VP_DIAG_NO_FRAME_IO
+    // DIAGNOSTIC (wrong results): the in-flight frame is neither read back nor written out -- what does that traffic cost?
+    if (false) {
+#else
     if (c.nChunk0 != 0) {
+#endif
         // a frame may be in flight (it is if the state says nAn != 0; if not, nothing reads what is loaded
         // here): its residual, the not yet filtered part of outEFrame (chunks >= nChunk0) and the last
         // `order` outputs (the IIR's history) are all that later chunks can read
@@ -2442,7 +2447,11 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         const lds_i32 *src = (const lds_i32 *)L.st;
         for (int i = tid; i < (int)(sizeof(VpPitchState) / sizeof(int)); i += nt) dst[i] = src[i];
     }
+#ifdef VP_DIAG_NO_FRAME_IO
+    if (false) {
+#else
     if (nChunk != 0 && L.st->nAn != 0) {
+#endif
         double *ge = d.eFrame + (size_t)s * g.eLen, *go = d.outEFrame + (size_t)s * g.F, *gy = d.yFrame + (size_t)s * g.F;
         const int done = nChunk * g.C;                       // same ranges as the load above
         for (int i = tid; i < g.eLen; i += nt) ge[i] = L.eF[i];

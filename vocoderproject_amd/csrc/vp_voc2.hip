@@ -196,74 +196,11 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
 }
 
 // ------------------------------------------------------------------------------------------------
-// levinson: lane = window, the reference's recursion as it stands (LPC.cpp:107-148) on per-lane columns in LDS
-// (a[k][lane], r[k][lane]: conflict-free).  The coefficient update is done on the pair (i, p - i) at once -- each new
-// value is old[i] - k * old[p - i], the same operands and operation as the reference's pass over a copy.
-// blockIdx.y = 0: voice (order sp.orderVoice), 1: side chain.  Dynamic LDS: 2 x (top + 1) x 64 doubles.
-__global__ __launch_bounds__(64) void vp_k_v2_levinson(VpGeom g, VpCall c, VpDev d, VpV2 v)
-{
-    extern __shared__ double smem[];
-    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
-    const bool isS = blockIdx.y != 0;
-    const V2Win q = v2_window(c, d, v, w);
-    if (!__any(q.live)) return;
-    const int top = isS ? v.oSmax : v.oVmax;                                // wave-uniform bound of the orders in this launch
-    lds_f64 *A = (lds_f64 *)smem + lane, *R = A + (size_t)(top + 1) * WAVE;  // column of this lane: X[k * WAVE]
-    const int order = isS ? q.oS : q.oV;
-    const int wc_ = q.b * c.nWin + q.j;
-    const V2Col rg = isS ? v2_col(v.rS, V2_RS_STRIDE, wc_) : v2_col(v.rV, V2_RV_STRIDE, wc_);
-    const V2Col ag = isS ? v2_col(v.aS, V2_RS_STRIDE, wc_) : v2_col(v.aV, V2_RV_STRIDE, wc_);
-    if (q.live)
-        for (int k = 0; k <= order; k++) R[k * WAVE] = rg[k];
-    if (q.live) {
-        const double r0 = R[0];
-        if (fabs(r0) < g.levEps) {                                          // :110-114
-            for (int k = 0; k <= order; k++) ag[k] = (k == 0) ? 1.0 : 0.0;
-        } else {
-            A[0] = 1.0;
-            A[WAVE] = R[WAVE] / r0;
-            for (int p = 2; p < order + 1; p++) {
-                double rho_a = 0.0, r_a = 0.0;
-                int i = 1;
-                for (; i + 4 <= p; i += 4) {                                // :120-128, four terms' operands read ahead of the ordered adds
-                    double ai[4], rp[4], ri[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { ai[t] = A[(i + t) * WAVE]; rp[t] = R[(p - i - t) * WAVE]; ri[t] = R[(i + t) * WAVE]; }
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { rp[t] = rp[t] * ai[t]; ri[t] = ri[t] * ai[t]; }
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { rho_a += rp[t]; r_a += ri[t]; }
-                }
-                for (; i < p; i++) {
-                    const double ai = A[i * WAVE];
-                    rho_a += R[(p - i) * WAVE] * ai;
-                    r_a += R[i * WAVE] * ai;
-                }
-                const double k = (R[p * WAVE] - rho_a) / (r0 - r_a);
-                i = 1;
-                for (; 2 * (i + 3) < p; i += 4) {                           // a[i] = aPrev[i] - k aPrev[p-i], both ends of four pairs
-                    double ai[4], aj[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { ai[t] = A[(i + t) * WAVE]; aj[t] = A[(p - i - t) * WAVE]; }
-#pragma unroll
-                    for (int t = 0; t < 4; t++) { A[(i + t) * WAVE] = ai[t] - k * aj[t]; A[(p - i - t) * WAVE] = aj[t] - k * ai[t]; }
-                }
-                for (; 2 * i <= p; i++) {
-                    const double ai = A[i * WAVE], aj = A[(p - i) * WAVE];
-                    A[i * WAVE] = ai - k * aj;
-                    if (2 * i != p) A[(p - i) * WAVE] = aj - k * ai;
-                }
-                A[p * WAVE] = k;
-            }
-            ag[0] = 1.0;
-            for (int k = 1; k <= order; k++) ag[k] = A[k * WAVE] * -1.;     // :145-146
-        }
-    }
-}
-
-// levinson, register-resident: the same recursion fully unrolled for orders up to P, coefficient and autocorrelation vectors
-// in registers (no LDS round trips in the two ordered sums: the LDS form above spends its time waiting for them).  A lane whose
-// own order is smaller steps out of the remaining order steps (EXEC mask).  Orders above V2_ORDER_MAX take the LDS form.
+// levinson: lane = window, the reference's recursion as it stands (LPC.cpp:107-148), fully unrolled for orders up to P with the
+// coefficient and autocorrelation vectors in registers (a first version kept them in per-lane LDS columns and spent its time
+// waiting for the round trips inside the two ordered sums: 47 us against 18 us at order 40).  The coefficient update is done
+// on the pair (i, p - i) at once -- each new value is old[i] - k * old[p - i], the same operands and operation as the
+// reference's pass over a copy.  A lane whose own order is smaller steps out of the remaining order steps (EXEC mask).
 template <int P>
 __global__ __launch_bounds__(64) void vp_k_v2_levinson_reg(VpGeom g, VpCall c, VpDev d, VpV2 v, int isS)
 {
@@ -603,6 +540,7 @@ __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, 
 // ------------------------------------------------------------------------------------------------
 // host side of the pipeline (called from vp_capi.hip's process_device)
 #define V2_LAUNCH(K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, st, __VA_ARGS__)
+#define V2_LAUNCH_ON(SX, K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, SX, __VA_ARGS__)
 
 template <int P> static void v2_launch_fir_t(dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
@@ -627,7 +565,6 @@ template <int P> static void v2_launch_iir_exact(dim3 grid, hipStream_t st, cons
 int vp_v2_init()
 {
     // dynamic-LDS ceilings of the two kernels that use it (process-wide function attributes)
-    if (hipFuncSetAttribute((const void *)vp_k_v2_levinson, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (VP_ORDER_MAX + 1) * 64 * 8) != hipSuccess) return -1;
     return 0;
 }
 
@@ -645,20 +582,21 @@ void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &
         const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
         V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
     }
-    auto lev = [&](int top, int isS) {
+    auto lev = [&](hipStream_t sx, int top, int isS) {
         switch ((top + 7) & ~7) {
-        case 8: V2_LAUNCH(vp_k_v2_levinson_reg<8>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 16: V2_LAUNCH(vp_k_v2_levinson_reg<16>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 24: V2_LAUNCH(vp_k_v2_levinson_reg<24>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 32: V2_LAUNCH(vp_k_v2_levinson_reg<32>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 40: V2_LAUNCH(vp_k_v2_levinson_reg<40>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        default: V2_LAUNCH(vp_k_v2_levinson_reg<48>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 8: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<8>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 16: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<16>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 24: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<24>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 32: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<32>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        case 40: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<40>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
+        default: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<48>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
         }
     };
-    if (getenv("VP_V2_LEV_LDS"))
-        V2_LAUNCH(vp_k_v2_levinson, dim3(nGroups, 2), dim3(64), 2 * (size_t)(std::max(v.oVmax, v.oSmax) + 1) * 64 * sizeof(double), g, c, d, v);
-    else { lev(v.oSmax, 1); lev(v.oVmax, 0); }
+    // (the side chain's kernels, orders <= 30 and usually 5, first.  Running them beside the voice's on a second stream was
+    // tried: +-1 % at 1024 streams, +2 % at the configs[4] geometry, -7 % when the pitch kernel runs beside the pipeline too)
     const dim3 gf(nGroups, (g.W + V2_FIR_SLICE - 1) / V2_FIR_SLICE);
+    lev(st, v.oSmax, 1);
+    lev(st, v.oVmax, 0);
     v2_launch_fir(v.oSmax, gf, st, g, c, d, v, 1);
     v2_launch_fir(v.oVmax, gf, st, g, c, d, v, 0);
     if (c.iirFast) {
