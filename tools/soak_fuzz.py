@@ -46,12 +46,59 @@ def lite_case(seed):
         assert np.abs(big).max() > 0.01, "vacuous comparison"
 
 
+def round2_case(seed):
+    """Round-2 features under random schedules: per-stream pitchBool / vocBool (cohorts), the lane-per-window vocoder
+    pipeline (forced or not), per-stream orders and gains, changed at random blocks -- every block bit-exact against one
+    oracle instance per stream."""
+    import numpy as np
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    rng = np.random.default_rng(31000 + seed)
+    fs = float(rng.choice([16000.0, 22050.0, 44100.0, 48000.0]))
+    N = int(rng.choice([128, 300, 512, 1024, 2048]))
+    S = int(rng.integers(3, 24))
+    B = max(8, int(14000 * fs / 44100.0) // N)
+    x = T._streams(S, N * B, fs=fs)
+    x[0, 0] *= np.where((np.arange(N * B) // 6000) % 2 == 0, 1.0, 2e-5).astype(np.float32)
+    base = dict(lpcVoice=int(rng.integers(2, 49)), lpcPitch=int(rng.integers(2, 40)), lpcSynth=int(rng.integers(2, 31)))
+    p = BatchVocoderProcessor(**base)
+    try:
+        p.prepareToPlay(fs, N, S)
+    except VpError as e:
+        assert e.code == -4, e
+        raise pytest.skip.Exception("geometry beyond the LDS budget")
+    p.set_vocoder_path(str(rng.choice(["batched", "workgroup", "batched"])))
+    os_ = []
+    for s_ in range(S):
+        o = O.OracleStream(**base)
+        o.prepare_to_play(fs, N)
+        os_.append(o)
+    choices = [("pitchBool", lambda: int(rng.random() < 0.6)), ("vocBool", lambda: int(rng.random() < 0.7)),
+               ("lpcVoice", lambda: int(rng.integers(2, 49))), ("lpcSynth", lambda: int(rng.integers(2, 31))),
+               ("keyPitch", lambda: int(rng.integers(0, 13))), ("gainVoc", lambda: float(rng.uniform(-20, 6))),
+               ("gainVoice", lambda: float(rng.choice([-60.0, -20.0]))), ("gainSynth", lambda: float(rng.choice([-60.0, -15.0])))]
+    for b in range(B):
+        for _ in range(int(rng.integers(0, 3))):
+            s_ = int(rng.integers(0, S)); k, f = choices[int(rng.integers(0, len(choices)))]; val = f()
+            p.setStreamParameter(s_, k, val)
+            os_[s_].set_param(k, val)
+        blk = np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])
+        got = p.process(blk)
+        for s_ in range(S):
+            io = blk[s_].copy()
+            os_[s_].process_block(io)
+            T._assert_equal(got[s_], io[:2], f"seed {seed}: fs={fs} N={N} S={S} block {b} stream {s_}")
+    ub = np.sum([o.ub_counters() for o in os_], axis=0)
+    assert list(p.ub_counters()) == list(ub)
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     ok = skipped = 0
     for seed in range(first, first + count):
-        fns = (lite_case,) if os.environ.get("VP_SOAK_LITE") else (T.test_randomised_configurations_bit_exact, T.test_randomised_configurations_with_extensions_bit_exact)
+        fns = (lite_case,) if os.environ.get("VP_SOAK_LITE") else (round2_case,) if os.environ.get("VP_SOAK_R2") else \
+              (T.test_randomised_configurations_bit_exact, T.test_randomised_configurations_with_extensions_bit_exact)
         for fn in fns:
             try:
                 fn(seed)

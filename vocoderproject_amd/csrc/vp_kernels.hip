@@ -887,7 +887,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
                 const lds_f32 *x = (isV ? xv : xsy) + m;
                 const lds_f64 *wm = win + m;
                 double sum = 0.0;
-                const int cnt = W - m, c8 = cnt & ~7;
+                const int cnt = max(W - m, 0), c8 = cnt & ~7;       // (a lag beyond the window -- order > W at low sample rates -- sums nothing: LPC.cpp:65)
                 for (int n = 0; n < c8; n += 8) {
                     double p_[8], w_[8]; float f_[8];
 #pragma unroll
@@ -1898,7 +1898,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
     const bool levLate = xcCert != 0;                 // Levinson-Durbin at the top of the marks phase instead of beside the running sum
     const int acM = min(nt - 1 - tid, g.orderPitch);                         // the last wavefront's lag per lane
     // how much of the sum runs beside YIN (the cross-correlation form of YIN is shorter: less fits beside it)
-    const int acSplit = min((g.F * (c.yinCert ? VP_XC_ACSPLIT : 15) / 16) & ~15, (g.F - g.orderPitch) & ~15);
+    const int acSplit = max(0, min((g.F * (c.yinCert ? VP_XC_ACSPLIT : 15) / 16) & ~15, (g.F - g.orderPitch) & ~15));   // (frames shorter than the order: nothing here)
     double acSum = 0.0;
     // computeYinTemp (PitchProcess.cpp:350-403): every lag is its own left-to-right sum over i.
     STAMPW_BEGIN();
@@ -2123,7 +2123,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         for (int m0 = nt - 1 - tid; (m0 & ~(WAVE - 1)) <= order && m0 >= 0; m0 += nt) {
             const int m = min(m0, order);
             double sum = 0.0;
-            const int cnt = g.F - m, c8 = cnt & ~7;
+            const int cnt = max(g.F - m, 0), c8 = cnt & ~7;
             const lds_f64 *xm = x + m;
             double a0[8], b0[8], a1[8], b1[8];              // same software pipeline as the YIN loop
 #define VP_ALOAD(A, B, I) _Pragma("unroll") for (int u = 0; u < 8; u++) { A[u] = x[(I) + u]; B[u] = xm[(I) + u]; }
@@ -2159,7 +2159,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         // if analysis marks exist
         STAMPL_BEGIN();
         const lds_f64 *x = L.xs + g.toKeep, *xm = x + acM;
-        const int nU = (g.F - g.orderPitch) & ~7;
+        const int nU = max(0, (g.F - g.orderPitch) & ~7);
         acSum = autocorr_stretch(x, acM, acSplit, nU, acSum);
         for (int n = nU; n < g.F - acM; n++) acSum += x[n] * xm[n];
         L.r[acM] = acSum / (double)g.F;                                       // spare lanes: identical stores

@@ -437,65 +437,85 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_exact(VpGeom g, VpCall c, VpDe
 // row broadcast of v_fmac_f64, the state crosses to the lower lane through a DPP row shift; four windows per wavefront.
 // With one lane per window a sample costs order + 1 dependent-issue slots and a launch has only NW / 64 wavefronts; this
 // way it costs T + 3 and there are sixteen times as many.  Differs from the exact chain by rounding only.
-template <int T>
+// NI: windows per row, interleaved step by step (two independent recursions in one instruction stream); NI = 2 does not pay
+// (the kernel is bound by issue, not by the chain's latency) and is not launched.
+template <int T, int NI>
 __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
     const int lane = threadIdx.x, m = lane & 15;
-    const int w = blockIdx.x * 4 + (lane >> 4);
-    const V2Win q = v2_window(c, d, v, w);
-    if (!__any(q.live)) return;
-    const int W = g.W, wc = q.b * c.nWin + q.j;
-    const int order = q.oV;
-    const V2ET<double> es = v2_e(v, 1, wc);
-    const V2Col ag = v2_col(v.aV, V2_RV_STRIDE, wc);
-    double *out = v.out + (size_t)wc * W;
-    const double gg = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
+    const int W = g.W;
     const double one = 1.0, zero = 0.0;
-    double na[T], st[T];
+    bool live[NI], any = false;
+    double gg[NI], na[NI][T], st[NI][T];
+    V2ET<double> es[NI];
+    double *out[NI];
 #pragma unroll
-    for (int j = 0; j < T; j++) { const int k = m * T + 1 + j; na[j] = (k <= order) ? -ag[k] : 0.0; st[j] = 0.0; }
+    for (int k = 0; k < NI; k++) {
+        const int w = (blockIdx.x * 4 + (lane >> 4)) * NI + k;
+        const V2Win q = v2_window(c, d, v, w);
+        const int wc = q.b * c.nWin + q.j;
+        live[k] = q.live;
+        any = any || q.live;
+        es[k] = v2_e(v, 1, wc);
+        out[k] = v.out + (size_t)wc * W;
+        gg[k] = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
+        const V2Col ag = v2_col(v.aV, V2_RV_STRIDE, wc);
+#pragma unroll
+        for (int j = 0; j < T; j++) { const int kk = m * T + 1 + j; na[k][j] = (kk <= q.oV) ? -ag[kk] : 0.0; st[k][j] = 0.0; }
+    }
+    if (!__any(any)) return;
     // Sixteen samples per trip: lane m of the row loads sample i + m (ONE load per trip, requested a trip ahead), the row
     // broadcast hands sample t to every lane, lane t keeps output t, one store per trip.
     // (g x for the sixteen samples of a trip is taken first, off the recursion's critical path: per sample the chain is
     // then  s_1 broadcast-add -> state update  and nothing else)
-#define V2_IF_GX(X, GX) { _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) GX[u_] = zero * zero; \
+#define V2_IF_GX(X, GX, G) { _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) GX[u_] = zero * zero; \
         double xx_ = X; asm volatile("s_nop 1" : "+v"(xx_)); \
-        VP_FMAC_BCAST(GX[0], xx_, gg, 0); VP_FMAC_BCAST(GX[1], xx_, gg, 1); VP_FMAC_BCAST(GX[2], xx_, gg, 2); VP_FMAC_BCAST(GX[3], xx_, gg, 3); \
-        VP_FMAC_BCAST(GX[4], xx_, gg, 4); VP_FMAC_BCAST(GX[5], xx_, gg, 5); VP_FMAC_BCAST(GX[6], xx_, gg, 6); VP_FMAC_BCAST(GX[7], xx_, gg, 7); \
-        VP_FMAC_BCAST(GX[8], xx_, gg, 8); VP_FMAC_BCAST(GX[9], xx_, gg, 9); VP_FMAC_BCAST(GX[10], xx_, gg, 10); VP_FMAC_BCAST(GX[11], xx_, gg, 11); \
-        VP_FMAC_BCAST(GX[12], xx_, gg, 12); VP_FMAC_BCAST(GX[13], xx_, gg, 13); VP_FMAC_BCAST(GX[14], xx_, gg, 14); VP_FMAC_BCAST(GX[15], xx_, gg, 15); }
-#define V2_IF_STEP(GXU, U, YOUT) { \
-        double yy = GXU;                                                    /* g x[i + U] */ \
-        double s0 = st[0]; \
+        VP_FMAC_BCAST(GX[0], xx_, G, 0); VP_FMAC_BCAST(GX[1], xx_, G, 1); VP_FMAC_BCAST(GX[2], xx_, G, 2); VP_FMAC_BCAST(GX[3], xx_, G, 3); \
+        VP_FMAC_BCAST(GX[4], xx_, G, 4); VP_FMAC_BCAST(GX[5], xx_, G, 5); VP_FMAC_BCAST(GX[6], xx_, G, 6); VP_FMAC_BCAST(GX[7], xx_, G, 7); \
+        VP_FMAC_BCAST(GX[8], xx_, G, 8); VP_FMAC_BCAST(GX[9], xx_, G, 9); VP_FMAC_BCAST(GX[10], xx_, G, 10); VP_FMAC_BCAST(GX[11], xx_, G, 11); \
+        VP_FMAC_BCAST(GX[12], xx_, G, 12); VP_FMAC_BCAST(GX[13], xx_, G, 13); VP_FMAC_BCAST(GX[14], xx_, G, 14); VP_FMAC_BCAST(GX[15], xx_, G, 15); }
+#define V2_IF_STEP(U) { _Pragma("unroll") for (int k = 0; k < NI; k++) { \
+        double yy = gx_[k][U];                                              /* g x[i + U] */ \
+        double s0 = st[k][0]; \
         asm volatile("s_nop 1" : "+v"(s0), "+v"(yy));                       /* VALU write -> DPP read */ \
         VP_FMAC_BCAST(yy, s0, one, 0);                                      /* + s_1, held by lane 0 of the row */ \
         const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s0), 0x101, 0xf, 0xf, false);    /* row_shl:1: lane m <- lane m + 1, */ \
         const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s0), 0x101, 0xf, 0xf, false);    /* 0 into the row's last lane      */ \
         const double in_ = __hiloint2double(hi_, lo_); \
-        _Pragma("unroll") for (int j = 0; j + 1 < T; j++) st[j] = __builtin_fma(na[j], yy, st[j + 1]); \
-        st[T - 1] = __builtin_fma(na[T - 1], yy, in_); \
-        if (m == (U)) YOUT = yy; }
-#define V2_IF_STEPS(GX, YO) \
-        V2_IF_STEP(GX[0], 0, YO) V2_IF_STEP(GX[1], 1, YO) V2_IF_STEP(GX[2], 2, YO) V2_IF_STEP(GX[3], 3, YO) V2_IF_STEP(GX[4], 4, YO) V2_IF_STEP(GX[5], 5, YO) \
-        V2_IF_STEP(GX[6], 6, YO) V2_IF_STEP(GX[7], 7, YO) V2_IF_STEP(GX[8], 8, YO) V2_IF_STEP(GX[9], 9, YO) V2_IF_STEP(GX[10], 10, YO) V2_IF_STEP(GX[11], 11, YO) \
-        V2_IF_STEP(GX[12], 12, YO) V2_IF_STEP(GX[13], 13, YO) V2_IF_STEP(GX[14], 14, YO) V2_IF_STEP(GX[15], 15, YO)
-#define V2_IF_TRIP(X, I) { double yo_ = 0.0, gx_[16]; V2_IF_GX(X, gx_) V2_IF_STEPS(gx_, yo_) if (q.live) out[(I) + m] = yo_; }
+        _Pragma("unroll") for (int j = 0; j + 1 < T; j++) st[k][j] = __builtin_fma(na[k][j], yy, st[k][j + 1]); \
+        st[k][T - 1] = __builtin_fma(na[k][T - 1], yy, in_); \
+        if (m == (U)) yo_[k] = yy; } }
+#define V2_IF_STEPS V2_IF_STEP(0) V2_IF_STEP(1) V2_IF_STEP(2) V2_IF_STEP(3) V2_IF_STEP(4) V2_IF_STEP(5) V2_IF_STEP(6) V2_IF_STEP(7) \
+        V2_IF_STEP(8) V2_IF_STEP(9) V2_IF_STEP(10) V2_IF_STEP(11) V2_IF_STEP(12) V2_IF_STEP(13) V2_IF_STEP(14) V2_IF_STEP(15)
+#define V2_IF_TRIP(X, I) { double yo_[NI], gx_[NI][16]; \
+        _Pragma("unroll") for (int k = 0; k < NI; k++) { yo_[k] = 0.0; V2_IF_GX(X[k], gx_[k], gg[k]) } \
+        V2_IF_STEPS \
+        _Pragma("unroll") for (int k = 0; k < NI; k++) if (live[k]) out[k][(I) + m] = yo_[k]; }
     const int W16 = W & ~15;
-    double xa = (W16 > 0) ? es[m] : 0.0, xb = 0.0;
+    double xa[NI], xb[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) { xa[k] = (W16 > 0) ? es[k][m] : 0.0; xb[k] = 0.0; }
     for (int i = 0; i < W16; i += 32) {
-        if (i + 16 < W16) xb = es[i + 16 + m];
+        if (i + 16 < W16) {
+#pragma unroll
+            for (int k = 0; k < NI; k++) xb[k] = es[k][i + 16 + m];
+        }
         V2_IF_TRIP(xa, i)
         if (i + 16 < W16) {
-            if (i + 32 < W16) xa = es[i + 32 + m];
+            if (i + 32 < W16) {
+#pragma unroll
+                for (int k = 0; k < NI; k++) xa[k] = es[k][i + 32 + m];
+            }
             V2_IF_TRIP(xb, i + 16)
         }
     }
     if (W16 < W) {                                                          // the ragged end: same steps, masked loads and stores
-        const double xr = (W16 + m < W) ? es[W16 + m] : 0.0;
-        double yo_ = 0.0, gx_[16];
-        V2_IF_GX(xr, gx_)
-        V2_IF_STEPS(gx_, yo_)
-        if (q.live && W16 + m < W) out[W16 + m] = yo_;
+        double xr[NI], yo_[NI], gx_[NI][16];
+#pragma unroll
+        for (int k = 0; k < NI; k++) { xr[k] = (W16 + m < W) ? es[k][W16 + m] : 0.0; yo_[k] = 0.0; V2_IF_GX(xr[k], gx_[k], gg[k]) }
+        V2_IF_STEPS
+#pragma unroll
+        for (int k = 0; k < NI; k++) if (live[k] && W16 + m < W) out[k][W16 + m] = yo_[k];
     }
 #undef V2_IF_GX
 #undef V2_IF_STEPS
@@ -601,12 +621,12 @@ void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &
     v2_launch_fir(v.oVmax, gf, st, g, c, d, v, 0);
     if (c.iirFast) {
         V2_LAUNCH(vp_k_v2_energy_slices, dim3(nGroups), dim3(64), 0, g, c, d, v);
+        // (two windows per row interleaved, NI = 2, was tried for few, long windows: 82 -> 133 us at the configs[4] geometry)
+        const int Tt = (v.oVmax + 15) / 16;
         const dim3 gi((NW + 3) / 4);
-        switch ((v.oVmax + 15) / 16) {
-        case 1: V2_LAUNCH(vp_k_v2_iir_fast<1>, gi, dim3(64), 0, g, c, d, v); break;
-        case 2: V2_LAUNCH(vp_k_v2_iir_fast<2>, gi, dim3(64), 0, g, c, d, v); break;
-        default: V2_LAUNCH(vp_k_v2_iir_fast<3>, gi, dim3(64), 0, g, c, d, v); break;
-        }
+        if (Tt <= 1) V2_LAUNCH((vp_k_v2_iir_fast<1, 1>), gi, dim3(64), 0, g, c, d, v);
+        else if (Tt == 2) V2_LAUNCH((vp_k_v2_iir_fast<2, 1>), gi, dim3(64), 0, g, c, d, v);
+        else V2_LAUNCH((vp_k_v2_iir_fast<3, 1>), gi, dim3(64), 0, g, c, d, v);
     } else {
         V2_LAUNCH(vp_k_v2_energy, dim3(nGroups, 2), dim3(64), 0, g, c, d, v);
         switch ((v.oVmax + 7) & ~7) {
