@@ -228,7 +228,7 @@ def main():
     import torch
     import torch.distributed as dist
     from vocoderproject_amd import BatchVocoderProcessor
-    from vocoderproject_amd.dist import gather_streams, scatter_streams
+    from vocoderproject_amd.dist import exchange_steps
     from vocoderproject_amd.synth import make_streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -246,7 +246,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
         rs = torch.tensor([float(rank)], dtype=torch.float64, device=dev)
         dist.all_reduce(rs, op=dist.ReduceOp.SUM)
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank_sum": float(rs.item()),
@@ -394,30 +395,15 @@ def main():
             xr = make_streams(Sg, N * U, fs=FS, first_stream=0, device=dev).view(Sg, 3, U, N).permute(2, 0, 1, 3)
             xr = (xr[:, :, 0, :] if mono else xr).contiguous()                     # [U][Sg][N] or [U][Sg][3][N]
             yr = [torch.empty((Sg, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
-        inb = [torch.empty((S, *tail_in), dtype=torch.float32, device=dev) for _ in range(2)]
-        outb = [torch.empty((S, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
         p.set_iir_mode(args.iir)
 
-        def wait(ws):
-            for w in ws or []:
-                w.wait()
-
         def run_exchange(steps):
-            wsc, wga = [None, None], [None, None]
-            _, wsc[0] = scatter_streams(xr[0] if rank == 0 else None, Sg, tail_in, torch.float32, dev, out=inb[0], async_op=True)
-            for i in range(steps):
-                cur = i & 1
-                wait(wsc[cur])
-                if i + 1 < steps:
-                    _, wsc[1 - cur] = scatter_streams(xr[(i + 1) % U] if rank == 0 else None, Sg, tail_in, torch.float32, dev,
-                                                      out=inb[1 - cur], async_op=True)
-                wait(wga[cur])                            # step i-2's gather has read outb[cur]
+            def proc(i_, o_):
                 if mono:
-                    p.process_mono_device(inb[cur], outb[cur], stream.cuda_stream)
+                    p.process_mono_device(i_, o_, stream.cuda_stream)
                 else:
-                    p.process_device(inb[cur], outb[cur], stream.cuda_stream)
-                _, wga[cur] = gather_streams(outb[cur], Sg, out=yr[cur] if rank == 0 else None, async_op=True)
-            wait(wga[0]); wait(wga[1])
+                    p.process_device(i_, o_, stream.cuda_stream)
+            exchange_steps(steps, Sg, (lambda i: xr[i % U]), (lambda i: yr[i & 1]), tail_in, (2, N), torch.float32, dev, proc)
 
         ke = max(16, args.steps // 2)
         run_exchange(4)

@@ -584,7 +584,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         const size_t NW = (size_t)S * h->nWinMax;
         if (h->nWinMax <= 64 && vp_v2_init() == 0) {
             h->v2.nGroupsMax = (int)((NW + 63) / 64);
-            h->v2.W4p = (W + 3) / 4 + 8;                                  // (+ padding: the autocorrelation reads a few samples ahead)
+            h->v2.W4p = (W + 3) / 4 + 16;                                 // (+ padding: the autocorrelation requests its samples two trips ahead)
             h->v2.W2p = (W + 1) / 2 + 2;
             RC(dev_alloc(h, &h->v2.xT, (size_t)2 * h->v2.nGroupsMax * h->v2.W4p * 256));
             RC(dev_alloc(h, &h->v2.eT, (size_t)2 * h->v2.nGroupsMax * h->v2.W2p * 128));

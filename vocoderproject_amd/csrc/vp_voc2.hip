@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         double R[16];
 #pragma unroll
         for (int t = 0; t < L; t++) R[t] = (double)x[m0 + t];
-        float4 au0, au1, ax0, ax1, bu0, bu1, bx0, bx1;
+        float4 au0, au1, ax0, ax1, bu0, bu1, bx0, bx1, cu0, cu1, cx0, cx1, du0, du1, dx0, dx1;
 #define V2_AC_LOAD(U0, U1, X0, X1, N) { U0 = *(const float4 *)&x.base[(size_t)((N) >> 2) * 256]; U1 = *(const float4 *)&x.base[(size_t)(((N) >> 2) + 1) * 256]; \
         X0 = *(const float4 *)&x.base[(size_t)(((N) + m0 + L) >> 2) * 256]; X1 = *(const float4 *)&x.base[(size_t)((((N) + m0 + L) >> 2) + 1) * 256]; }
 #define V2_AC_TRIP(PH, U0, U1, X0, X1, N) { \
@@ -161,15 +161,24 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * wl[(N) + t];                 /* tmp, LPC.cpp:61 */ \
         _Pragma("unroll") for (int t = 0; t < 8; t++) { \
             _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * R[(t + j + PH) & 15]; p = p * wl[(N) + t + m0 + j]; sum[j] += p; } } }
+        // (requests run TWO trips ahead -- four named buffer sets, four trips per loop iteration: with one or two wavefronts
+        // per SIMD a trip of 0.2-0.4 us does not cover a memory round trip)
         V2_AC_LOAD(au0, au1, ax0, ax1, 0)
-        for (int n = 0; n < nMain; n += 16) {
-            V2_AC_LOAD(bu0, bu1, bx0, bx1, n + 8)
+        V2_AC_LOAD(bu0, bu1, bx0, bx1, 8)
+        for (int n = 0; n < nMain; n += 32) {
+            V2_AC_LOAD(cu0, cu1, cx0, cx1, n + 16)
             V2_AC_TRIP(0, au0, au1, ax0, ax1, n)
             if (n + 8 < nMain) {
-                V2_AC_LOAD(au0, au1, ax0, ax1, n + 16)
+                V2_AC_LOAD(du0, du1, dx0, dx1, n + 24)
                 V2_AC_TRIP(8, bu0, bu1, bx0, bx1, n + 8)
-            } else {
-                // (an odd number of trips: keep the ring's phase for nobody -- the tail below reads memory)
+            }
+            if (n + 16 < nMain) {
+                V2_AC_LOAD(au0, au1, ax0, ax1, n + 32)
+                V2_AC_TRIP(0, cu0, cu1, cx0, cx1, n + 16)
+            }
+            if (n + 24 < nMain) {
+                V2_AC_LOAD(bu0, bu1, bx0, bx1, n + 40)
+                V2_AC_TRIP(8, du0, du1, dx0, dx1, n + 24)
             }
         }
 #undef V2_AC_LOAD

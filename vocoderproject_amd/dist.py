@@ -83,3 +83,38 @@ def gather_streams(y_local, n_streams, dst=0, group=None, out=None, async_op=Fal
     lo, hi = shard_range(n_streams, rank, world)
     works = _run([dist.P2POp(dist.isend, y_local.contiguous(), _global_rank(group, dst), group)], async_op) if hi > lo else []
     return (None, works) if async_op else None
+
+
+def exchange_steps(n_steps, n_streams, in_root, out_root, in_tail, out_tail, dtype, device, process, root=0, group=None):
+    """SURVEY 8(e), double-buffered: per step the root fans block `in_root(i)` ([n_streams, *in_tail], root only) out to the
+    ranks, every rank runs `process(in_shard, out_shard)` on its own shard, the root gathers [n_streams, *out_tail] into
+    `out_root(i)` (root only; may return None to let the helper allocate).  Step i+1's scatter and step i-1's gather are in
+    flight while step i is processed.  Returns the list of the root's output tensors of the last two steps (root) or None.
+    Every rank must call it with the same n_steps."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_streams, rank, world)
+    inb = [torch.empty((hi - lo, *in_tail), dtype=dtype, device=device) for _ in range(2)]
+    outb = [torch.empty((hi - lo, *out_tail), dtype=dtype, device=device) for _ in range(2)]
+    wsc, wga, res = [None, None], [None, None], [None, None]
+
+    def wait(ws):
+        for w in ws or []:
+            w.wait()
+
+    if n_steps <= 0:
+        return None
+    _, wsc[0] = scatter_streams(in_root(0) if rank == root else None, n_streams, in_tail, dtype, device, src=root, group=group,
+                                out=inb[0], async_op=True)
+    for i in range(n_steps):
+        cur = i & 1
+        wait(wsc[cur])
+        if i + 1 < n_steps:
+            _, wsc[1 - cur] = scatter_streams(in_root(i + 1) if rank == root else None, n_streams, in_tail, dtype, device, src=root,
+                                              group=group, out=inb[1 - cur], async_op=True)
+        wait(wga[cur])                                # step i-2's gather has read outb[cur]
+        process(inb[cur], outb[cur])
+        res[cur], wga[cur] = gather_streams(outb[cur], n_streams, dst=root, group=group,
+                                            out=out_root(i) if rank == root else None, async_op=True)
+    wait(wga[0])
+    wait(wga[1])
+    return res if rank == root else None
