@@ -349,10 +349,11 @@ def main():
     if not args.single_mode:
         dt_other, _ = timed(other, k2, max(2, args.warmup // 4))
     # a second secondary figure: the same blocks handed over eight at a time (vp_process_blocks_device: one launch per eight
-    # blocks in pitch mode, state stays on chip in between); reported beside `value`, never as it
+    # blocks in pitch mode, state stays on chip in between; one launch of the lane-per-window pipeline with eight times the
+    # windows in vocoder mode); reported beside `value`, never as it
     MB, k3 = 8, max(4, args.steps // 16)
     dt_mb = float("nan")
-    if not args.single_mode and BPS == 1 and mode == "pitch" and U % MB == 0:
+    if not args.single_mode and BPS == 1 and mode in ("pitch", "voc") and U % MB == 0:
         ymb = torch.empty((MB, S, 2, N), dtype=torch.float32, device=dev)
         p.set_iir_mode(args.iir)
 

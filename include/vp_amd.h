@@ -131,8 +131,11 @@ int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_o
 /* n_blocks consecutive processBlock() calls at once (offline rendering, servers with audio queued up):
  * d_in float [n_blocks][n_streams][3][N], d_out float [n_blocks][n_streams][2][N], i.e. block b's slabs are what
  * vp_process_block_device would take.  Results are identical to n_blocks single calls.  With the pitch corrector alone
- * enabled the blocks run in ONE launch (tracker state and the frame in flight stay on chip between them); other
- * plans are issued block by block.  Parameters are read once, at entry. */
+ * enabled the blocks run in ONE launch (tracker state and the frame in flight stay on chip between them); with the
+ * vocoder alone (LPC orders <= 48, any batch size) groups of up to 16 blocks run as ONE launch of the lane-per-window
+ * pipeline -- the window grid carries across blocks, so B blocks are B times the windows, i.e. B times the lanes; every block
+ * keeps its own ring ingest, silence gate and output slab (256 streams, 8 blocks per call: 2.1x the single-call throughput,
+ * 3x in exact mode); the combined plan is issued block by block.  Parameters are read once, at entry. */
 int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream);
 /* The same from HOST memory: in float [n_blocks][n_streams][3][N], out float [n_blocks][n_streams][2][N]; one upload,
  * the blocks, one download, synchronises before returning (staging buffers grow on demand; VP_ERR_OOM). */

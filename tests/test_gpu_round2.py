@@ -536,3 +536,56 @@ def test_lpc_order_beyond_the_window_length(fs, N, params):
         p.prepareToPlay(fs, N, S)
         p.set_vocoder_path(path)
         _assert_equal(p.run(x), ref, f"fs={fs} N={N} {params} [{p.vocoder_kernel_name()}]")
+
+
+@pytest.mark.parametrize("N,iir", [(1024, "exact"), (300, "exact"), (100, "exact"), (1024, "fast"), (512, "fast")])
+def test_vocoder_multi_block_launch_equals_block_by_block(N, iir):
+    """SURVEY 8(f2) for the vocoder: vp_process_blocks_device with the vocoder-only plan runs up to 16 blocks as ONE launch of
+    the lane-per-window pipeline (B times the windows = B times the lanes).  The window grid carries across blocks, every
+    block keeps its own ring ingest, silence gate and output slab: B blocks in one call must give exactly what B single
+    calls give (and, in exact mode, what the oracle gives) -- gate crossings (whole blocks gated in the middle of a
+    launch), dry voice and dry carrier on (their samples come from the ring as it stood before the call, or from the
+    input slabs), host blocks smaller than the hop (blocks without a window of their own), odd splits."""
+    import torch
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    S = 6
+    B = 48 if N >= 512 else 96
+    x = _streams(S, N * B)
+    x[0, 0] *= np.where((np.arange(N * B) // 5000) % 2 == 0, 1.0, 1e-5).astype(np.float32)          # gate crossings
+    x[1, 1] *= np.where((np.arange(N * B) // 7000) % 2 == 0, 1.0, 1e-5).astype(np.float32)          # ... of the carrier
+    x[:, 2] *= -0.5
+    params = dict(pitchBool=0, gainVoice=-6.0, gainSynth=-9.0, lpcVoice=24, lpcSynth=7)
+    xb = torch.from_numpy(np.ascontiguousarray(x.reshape(S, 3, B, N).transpose(2, 0, 1, 3))).cuda()      # [B][S][3][N]
+
+    def run(split, path="batched"):
+        p = BatchVocoderProcessor(**params)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode(iir)
+        p.set_vocoder_path(path)
+        y = torch.full((B, S, 2, N), float("nan"), dtype=torch.float32, device="cuda")
+        b = 0
+        for n in split:
+            p.process_blocks_device(xb[b:b + n].contiguous(), y[b:b + n])
+            b += n
+        assert b == B
+        torch.cuda.synchronize()
+        return y.cpu().numpy().transpose(1, 2, 0, 3).reshape(S, 2, B * N)
+
+    single = run([1] * B)
+    assert np.isfinite(single).all()
+    for split in ([B], [16] * (B // 16), [5, 1, 7, 3] * (B // 16), [2] * (B // 2), [1, 15] * (B // 16)):
+        got = run(split)
+        if iir == "exact":
+            _assert_equal(got, single, f"N={N} split {split[:4]}...")
+        else:
+            assert np.abs(got - single).max() < 1e-5 and np.isfinite(got).all()     # FAST: slice energies sum in the same order: identical or rounding-level
+    if iir == "exact":
+        ref = []
+        for s_ in range(S):
+            o = O.OracleStream(**params)
+            o.prepare_to_play(FS, N)
+            ref.append(o.run(x[s_]))
+        _assert_equal(single, np.stack(ref), "single calls vs oracle")
+        _assert_equal(run([B]), np.stack(ref), "one launch group vs oracle")
+        _assert_equal(run([B], path="workgroup"), np.stack(ref), "workgroup path (block by block)")

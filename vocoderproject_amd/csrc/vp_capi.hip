@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vp_amd.h"
@@ -42,6 +43,9 @@ struct vp_handle {
     // the batched lane-per-window vocoder pipeline (vp_voc2.hip): scratch, the orders it must cover, and who picks it
     VpV2 v2;
     int vocPath = VP_VOC_AUTO, oVmax = 0, oSmax = 0, nWinMax = 0;
+    VpV2 v2mb;                                  // the same scratch sized for several blocks per launch (allocated on first use)
+    int v2mbWin = 0;                            // windows per stream it holds
+    std::vector<void *> mbAllocs;
     // vp_set_overlap(h, 1), VP_IIR_FAST, both processes on, batched vocoder: the pitch kernel runs beside the vocoder pipeline on
     // auxStream and adds into its own accumulator (acc2), which emit merges.  acc2Live: blocks for which acc2 may still hold
     // something.  Off by default: measured 404 vs 408 us per block at 1024 streams, 880 vs 820 us at the configs[4] geometry --
@@ -241,6 +245,8 @@ static void free_all(vp_handle *h)
     for (void *p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
     h->stageIn = h->stageOut = nullptr; h->dMapAll = nullptr; h->cohorts.clear(); h->acc2 = nullptr;
+    for (void *p : h->mbAllocs) (void)hipFree(p);
+    h->mbAllocs.clear(); h->v2mbWin = 0; memset(&h->v2mb, 0, sizeof h->v2mb); memset(&h->v2, 0, sizeof h->v2);
     if (h->stageInB) (void)hipFree(h->stageInB);
     if (h->stageOutB) (void)hipFree(h->stageOutB);
     h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
@@ -595,6 +601,8 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
             RC(dev_alloc(h, &h->v2.rS, NWp * V2_RS_STRIDE));
             RC(dev_alloc(h, &h->v2.aS, NWp * V2_RS_STRIDE));
             RC(dev_alloc(h, &h->v2.meta, NWp));
+            RC(dev_alloc(h, &h->v2.rank, NWp + S));
+            RC(dev_alloc(h, &h->v2.liveList, NWp));
             RC(dev_alloc(h, &h->v2.EE, NW * 2));
             h->v2.nSlices = (W + V2_FIR_SLICE - 1) / V2_FIR_SLICE;
             RC(dev_alloc(h, &h->v2.EEp, NW * 2 * h->v2.nSlices));
@@ -894,6 +902,95 @@ extern "C" int vp_process_block_device(vp_handle *h, const float *d_in, float *d
     return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0);
 }
 
+// scratch of the batched vocoder pipeline for `nWin` windows per stream (multi-block launches), grown on demand
+static int ensure_v2mb(vp_handle *h, int nWin)
+{
+    if (nWin <= h->v2mbWin) return VP_OK;
+    for (void *p : h->mbAllocs) (void)hipFree(p);
+    h->mbAllocs.clear(); h->v2mbWin = 0;
+    const VpGeom &g = h->g;
+    VpV2 v;
+    memset(&v, 0, sizeof v);
+    const size_t NW = (size_t)g.S * nWin;
+    v.nGroupsMax = (int)((NW + 63) / 64);
+    v.W4p = h->v2.W4p; v.W2p = h->v2.W2p; v.nSlices = h->v2.nSlices;
+    const size_t NWp = (size_t)v.nGroupsMax * 64;
+    auto get = [&](auto **p, size_t count) -> bool {
+        void *q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(**p)) != hipSuccess) return false;
+        h->mbAllocs.push_back(q);
+        (void)hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(**p));
+        *p = (std::remove_reference_t<decltype(**p)> *)q;
+        return true;
+    };
+    const bool ok = get(&v.xT, (size_t)2 * v.nGroupsMax * v.W4p * 256) && get(&v.eT, (size_t)2 * v.nGroupsMax * v.W2p * 128) &&
+                    get(&v.out, NW * g.W) && get(&v.rV, NWp * V2_RV_STRIDE) && get(&v.aV, NWp * V2_RV_STRIDE) &&
+                    get(&v.rS, NWp * V2_RS_STRIDE) && get(&v.aS, NWp * V2_RS_STRIDE) && get(&v.meta, NWp) && get(&v.rank, NWp + g.S) &&
+                    get(&v.liveList, NWp) && get(&v.EE, NW * 2) && get(&v.EEp, NW * 2 * v.nSlices) && get(&v.dry, (size_t)g.S * 3 * g.latency);
+    if (!ok) {
+        for (void *p : h->mbAllocs) (void)hipFree(p);
+        h->mbAllocs.clear();
+        h->lastError = "out of device memory for the multi-block vocoder scratch";
+        return VP_ERR_OOM;
+    }
+    h->v2mb = v;
+    h->v2mbWin = nWin;
+    return VP_OK;
+}
+
+// vp_process_blocks_device, vocoder-only plan on the batched pipeline: up to V2_MB_MAX consecutive blocks as ONE launch of the
+// pipeline (B times the windows = B times the lanes; vp_voc2.hip).  Returns VP_OK + *done = false when the plan does not apply.
+static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int nb, hipStream_t st, bool *done)
+{
+    *done = false;
+    const VpGeom &g = h->g;
+    if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX) return VP_OK;
+    auto &co = h->cohorts[0];
+    if (!co.vocOn || co.pitchOn || !h->v2.xT || h->vocPath == VP_VOC_WORKGROUP) return VP_OK;
+    if (h->oVmax > V2_ORDER_MAX || h->oSmax > VP_ORDER_MAX_SYNTH || h->oVmax < 2 || h->oSmax < 2) return VP_OK;
+    VpV2MB mb;
+    memset(&mb, 0, sizeof mb);
+    mb.nBlocks = nb;
+    int vs = co.vStart, NWs = 0;
+    for (int b = 0; b < nb; b++) {                                           // VocoderProcess.cpp:173-183 block after block
+        const int nWin = (vs < g.N) ? (g.N - vs + g.h - 1) / g.h : 0;
+        mb.vStart[b] = vs; mb.nWin[b] = nWin; mb.first[b] = NWs;
+        NWs += nWin;
+        vs = vs + nWin * g.h - g.N;
+    }
+    if (NWs < 1 || mb.nWin[0] < 1) return VP_OK;                             // (the launch's coordinates hang on block 0's first window)
+    // the grid is continuous: window k starts at vStart[0] + k h (in block-0 coordinates)
+    for (int b = 1; b < nb; b++)
+        if (mb.nWin[b] > 0 && b * g.N + mb.vStart[b] != mb.vStart[0] + mb.first[b] * g.h) return VP_OK;
+    if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
+    int rc = ensure_v2mb(h, NWs);
+    if (rc) return rc;
+    h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
+    VpCall c;
+    memset(&c, 0, sizeof c);
+    c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
+    c.iirFast = h->iirMode; c.nBlocks = nb; c.inMono = 0; c.vocOn = 1; c.pitchOn = 0;
+    c.vStart = mb.vStart[0]; c.nWin = NWs; c.fuseIngest = 1; c.fuseEmit = 1;
+    VpDev d = h->d;
+    d.streamMap = co.dMap;
+    d.outAcc2 = h->acc2Live > 0 ? h->acc2 : nullptr;
+    VpV2 v = h->v2mb;
+    v.nStreams = co.n; v.oVmax = h->oVmax; v.oSmax = h->oSmax;
+    { ProfScope ps(h, st, 1); vp_v2_launch_blocks(g, c, d, v, mb, d_in, d_out, st); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->poisoned = true; return fail_hip(h, e, "kernel launch"); }
+    co.vStart = vs;
+    h->synthNonZero = g.inSize;
+    h->acc2Live = std::max(0, h->acc2Live - nb);
+    for (int b = 0; b < nb; b++) {                                           // MyBuffer.cpp:129-132
+        h->outCounter = (h->outCounter + g.N) % g.outSize;
+        h->inCounter = (h->inCounter + g.N) % g.inSize;
+        h->currCounter = (h->currCounter + g.N) % g.inSize;
+    }
+    *done = true;
+    return VP_OK;
+}
+
 static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream, bool mono)
 {
     if (!h || !d_in || !d_out || n_blocks < 1) return VP_ERR_INVALID_ARG;
@@ -907,6 +1004,19 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     if (pitchOnly && n_blocks > 1 && !fft && !pitch_lite(h, fast, fft))      // one launch: state stays on chip between the blocks
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
     const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
+    if (!mono && n_blocks > 1) {                               // vocoder-only plan on the batched pipeline: groups of blocks per launch
+        int b = 0;
+        while (b < n_blocks) {
+            const int nb = std::min(n_blocks - b, V2_MB_MAX);
+            bool done = false;
+            rc = process_voc_blocks(h, d_in + b * nIn, d_out + b * nOut, nb, (hipStream_t)hip_stream, &done);
+            if (rc) return rc;
+            if (!done) break;
+            b += nb;
+        }
+        if (b == n_blocks) return VP_OK;
+        d_in += b * nIn; d_out += b * nOut; n_blocks -= b;     // (a remainder of one block, or a plan that does not apply)
+    }
     for (int b = 0; b < n_blocks; b++) {                       // other plans: block by block
         rc = process_device(h, d_in + b * nIn, d_out + b * nOut, (hipStream_t)hip_stream, 0, 1, mono);
         if (rc) return rc;

@@ -15,6 +15,9 @@ struct VpV2 {
     double *rV, *rS;            // [nGroupsMax][V2_RV_STRIDE][64], [nGroupsMax][V2_RS_STRIDE][64]   autocorrelations (lag-major tiles)
     double *aV, *aS;            // same shapes: A(z) coefficients
     int4 *meta;                 // [NW] per window: gate open, lpcVoice, lpcSynth, stream
+    int *rank;                  // [NW] 1-based rank of the window among the stream's LIVE windows of this launch (0: gated)
+    int *liveList;              // [NW] per stream: window index of its q-th live window
+    float *dry;                 // [S][3][latency] multi-block launches: the samples of the dry paths that only the ring held
     double *eT;                 // [2][nGroupsMax][W2p][64][2]  residuals (voice, side chain), transposed tiles
     double *out;                // [NW][W] the all-pole output, window-major
     int nGroupsMax, W4p, W2p;   // 64-window groups the scratch holds; float4 / double2 rows per window (padded)
@@ -25,7 +28,13 @@ struct VpV2 {
     int oVmax, oSmax;           // largest lpcVoice / lpcSynth over the streams (the orders themselves are per stream)
 };
 
+// multi-block launches (vp_process_blocks_device, vocoder-only plan): per block of the launch
+#define V2_MB_MAX 16
+struct VpV2MB { int nBlocks, vStart[V2_MB_MAX], nWin[V2_MB_MAX], first[V2_MB_MAX]; };
+
 int vp_v2_init();
+void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const VpV2MB &mb, const float *d_in, float *d_out,
+                         hipStream_t st);
 // `afterIngest` (optional) is called right behind the launch of the ingest+gate+stage kernel (what the caller wants to start beside the rest)
 void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
                   void (*afterIngest)(void *) = nullptr, void *hookArg = nullptr);

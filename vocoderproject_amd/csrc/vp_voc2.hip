@@ -87,7 +87,10 @@ __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c,
     const int W4 = (g.W + 3) >> 2;
     if ((int)threadIdx.x < c.nWin) {
         const VpStreamParams sp = d.pitch[s].sp;
-        v.meta[b * c.nWin + threadIdx.x] = make_int4(d.gate[s * 2 + 0] && d.gate[s * 2 + 1], sp.orderVoice, sp.orderSynth, s);
+        const int live = d.gate[s * 2 + 0] && d.gate[s * 2 + 1];
+        v.meta[b * c.nWin + threadIdx.x] = make_int4(live, sp.orderVoice, sp.orderSynth, s);
+        v.rank[b * c.nWin + threadIdx.x] = live ? (int)threadIdx.x + 1 : 0;
+        v.liveList[b * c.nWin + threadIdx.x] = threadIdx.x;
     }
     for (int t = threadIdx.x; t < c.nWin * W4; t += blockDim.x) {
         const int i4 = t / c.nWin, j = t - i4 * c.nWin;                       // window fastest: the stream's windows are adjacent lanes of the tile
@@ -388,10 +391,12 @@ __global__ __launch_bounds__(64) void vp_k_v2_energy(VpGeom g, VpCall c, VpDev d
 // The 10-deep energy histories as they stand right after window j of the block was pushed (VocoderProcess.cpp:264-268):
 // its own energies, the block's earlier windows (newest first), then what the stream carried in (EeArr).
 // entry t of history `which` (0 voice, 1 side chain)
+// (a launch of several blocks can have gated blocks in between: only LIVE windows push, so "t windows back" goes through the
+// stream's list of live windows; with one block per launch that list is simply 0, 1, 2, ...)
 __device__ __forceinline__ double v2_hist_entry(const VpDev &d, const VpV2 &v, int s, int wBase, int j, int t, int which)
 {
-    const int jj = j - t;                                                   // window of this block, or history entry -jj - 1
-    return (jj >= 0) ? v.EE[(size_t)(wBase + jj) * 2 + which] : d.EeArr[(size_t)s * 20 + which * 10 - jj - 1];
+    const int rr = v.rank[wBase + j] - 1 - t;                               // rank of the wanted live window, or history entry -rr - 1
+    return (rr >= 0) ? v.EE[(size_t)(wBase + v.liveList[wBase + rr]) * 2 + which] : d.EeArr[(size_t)s * 20 + which * 10 - rr - 1];
 }
 __device__ __forceinline__ void v2_histories(const VpDev &d, const VpV2 &v, int s, int wBase, int j, double hv[10], double hs[10])
 {
@@ -567,6 +572,128 @@ __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Several consecutive blocks in one launch of the pipeline (vp_process_blocks_device, vocoder-only plan): the window grid is
+// continuous in stream time (startSample carries from block to block, VocoderProcess.cpp:176-182), so B blocks are simply
+// B times as many windows per stream -- B times as many lanes for every kernel above -- with three things per BLOCK:
+// the ring it is ingested into, its own silence gate (the whole-ring RMS after ITS ingest) and its own output slab.
+// Logical index L counts samples from block 0's index 0: L < latency comes from the ring as it stood before this call,
+// anything later straight from the input slabs (the ring cannot hold more than a block or two).
+
+// sample of channel ch (0 voice, 1/2 side chain) at logical index L >= 0, before any of this call's blocks was ingested
+__device__ __forceinline__ float v2_mb_src(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in, int s, int ch, int L)
+{
+    if (L < g.latency) {
+        const float *ring = (ch == 0) ? d.voiceRing + (size_t)s * g.inSize : d.synthRing + ((size_t)s * 2 + (ch - 1)) * g.inSize;
+        return ring[ring_pos(c.currCounter, L, g.inSize)];
+    }
+    const int bl = (L - g.latency) / g.N, off = (L - g.latency) - bl * g.N;
+    return in[(((size_t)bl * g.S + s) * 3 + ch) * g.N + off];
+}
+
+__global__ __launch_bounds__(256) void vp_k_v2_mb_ingest_stage(VpGeom g, VpCall c, VpDev d, VpV2 v, VpV2MB mb, const float *__restrict__ in)
+{
+    __shared__ int gl[V2_MB_MAX];
+    const int s = vp_stream(d), b = blockIdx.x, tid = threadIdx.x;
+    const int NWs = c.nWin;                                                 // windows per stream in this launch
+    // a. every window of the launch into the tiles, and the ring-held part of the dry paths' samples
+    const int W4 = (g.W + 3) >> 2;
+    for (int t = tid; t < NWs * W4; t += blockDim.x) {
+        const int i4 = t / NWs, k = t - i4 * NWs;
+        const int w = b * NWs + k;
+        const int L0 = mb.vStart[0] + k * g.h + 4 * i4;
+        float a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool inw = 4 * i4 + u < g.W;
+            a4[u] = inw ? v2_mb_src(g, c, d, in, s, 0, L0 + u) : 0.0f;
+            b4[u] = inw ? v2_mb_src(g, c, d, in, s, 1, L0 + u) : 0.0f;
+        }
+        float *xv = v.xT + ((((size_t)(w >> 6)) * v.W4p + i4) * 64 + (w & 63)) * 4;
+        float *xs = xv + (size_t)v.nGroupsMax * v.W4p * 256;
+        *(float4 *)xv = make_float4(a4[0], a4[1], a4[2], a4[3]);
+        *(float4 *)xs = make_float4(b4[0], b4[1], b4[2], b4[3]);
+    }
+    for (int t = tid; t < 3 * g.latency; t += blockDim.x) {
+        const int ch = t / g.latency, L = t - ch * g.latency;
+        v.dry[((size_t)b * 3 + ch) * g.latency + L] = v2_mb_src(g, c, d, in, s, ch, L);
+    }
+    __syncthreads();
+    // b. the blocks into the ring one after the other, each with its own gate (MyBuffer.cpp:74-105, VocoderProcess.cpp:199-204)
+    for (int bl = 0; bl < mb.nBlocks; bl++) {
+        ingest_gate_block(g, c, d, in + (size_t)bl * g.S * 3 * g.N, bl * g.N);
+        if (tid == 0) gl[bl] = d.gate[s * 2 + 0] && d.gate[s * 2 + 1];
+        __syncthreads();
+    }
+    // c. the windows' records: gate of their block, orders, rank among the stream's live windows
+    if (tid == 0) {
+        const VpStreamParams sp = d.pitch[s].sp;
+        int nLive = 0, bl = 0;
+        for (int k = 0; k < NWs; k++) {
+            while (bl + 1 < mb.nBlocks && k >= mb.first[bl + 1]) bl++;
+            const int live = gl[bl];
+            v.meta[b * NWs + k] = make_int4(live, sp.orderVoice, sp.orderSynth, s);
+            v.rank[b * NWs + k] = live ? nLive + 1 : 0;
+            if (live) v.liveList[b * NWs + nLive++] = k;
+        }
+        v.rank[(size_t)v.nGroupsMax * 64 + b] = nLive;                       // (the stream's live count, behind the per-window ranks)
+    }
+}
+
+// overlap-add of every window of the launch in window order + emit of every block (VocoderProcess.cpp:291-295,
+// MyBuffer.cpp:113-133, 309-448); what reaches beyond the last block is left in the accumulator ring for the next call.
+// Dynamic LDS: outSize doubles.
+__global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, VpDev d, VpV2 v, VpV2MB mb, const float *__restrict__ in,
+                                                            float *__restrict__ out)
+{
+    extern __shared__ double smem[];
+    lds_f64 *tail = (lds_f64 *)smem;
+    const int s = vp_stream(d), b = blockIdx.x, tid = threadIdx.x;
+    const int NWs = c.nWin, wBase = b * NWs, W = g.W, BN = mb.nBlocks * g.N, v0 = mb.vStart[0];
+    const VpStreamParams sp = d.pitch[s].sp;
+    const double gainVoc = sp.gainVoc;
+    double *acc = d.outAcc + (size_t)s * g.outSize;
+    double *acc2 = d.outAcc2 ? d.outAcc2 + (size_t)s * g.outSize : nullptr;
+    const double *o = v.out + (size_t)wBase * W;
+    for (int t = tid; t < BN + g.outSize; t += blockDim.x) {
+        double val = 0.0;
+        if (t < g.outSize) {
+            const int pos = (c.outCounter + t) % g.outSize;
+            val = acc[pos];
+            if (acc2) val += acc2[pos];
+        }
+        if (NWs > 0 && t >= v0) {
+            const int klo = max(0, (t - v0 - W + g.h) / g.h), khi = min(NWs - 1, (t - v0) / g.h);
+            for (int k = klo; k <= khi; k++) {
+                const int i = t - v0 - k * g.h;
+                if (i >= 0 && i < W && v.meta[wBase + k].x) val += gainVoc * o[(size_t)k * W + i] * d.vocWin[i];
+            }
+        }
+        if (t < BN) {
+            const int bl = t / g.N, i = t - bl * g.N;
+            auto smp = [&](int ch) -> double { return (double)((t < g.latency) ? v.dry[((size_t)b * 3 + ch) * g.latency + t] : v2_mb_src(g, c, d, in, s, ch, t)); };
+            if (sp.dryOn) val += smp(0) * sp.gainVoice;
+            double l = val, r = val;
+            if (sp.synthOn) { l += smp(1) * sp.gainSynth; r += smp(2) * sp.gainSynth; }
+            float *ob = out + (((size_t)bl * g.S + s) * 2) * g.N;
+            ob[i] = (float)l;
+            ob[g.N + i] = (float)r;
+        } else
+            tail[t - BN] = val;
+    }
+    __syncthreads();
+    for (int u = tid; u < g.outSize; u += blockDim.x) {
+        const int pos = (c.outCounter + BN + u) % g.outSize;
+        acc[pos] = tail[u];
+        if (acc2) acc2[pos] = 0.0;
+    }
+    const int nLive = v.rank[(size_t)v.nGroupsMax * 64 + b];
+    if (tid < 20 && nLive > 0) {                                             // the last live window leaves the histories behind
+        const double hnew = v2_hist_entry(d, v, s, wBase, v.liveList[wBase + nLive - 1], tid % 10, tid / 10);
+        d.EeArr[(size_t)s * 20 + tid] = hnew;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side of the pipeline (called from vp_capi.hip's process_device)
 #define V2_LAUNCH(K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, st, __VA_ARGS__)
 #define V2_LAUNCH_ON(SX, K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, SX, __VA_ARGS__)
@@ -593,16 +720,16 @@ template <int P> static void v2_launch_iir_exact(dim3 grid, hipStream_t st, cons
 
 int vp_v2_init()
 {
+    if (hipFuncSetAttribute((const void *)vp_k_v2_mb_ola_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
     // dynamic-LDS ceilings of the two kernels that use it (process-wide function attributes)
     return 0;
 }
 
-void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
-                  void (*afterIngest)(void *), void *hookArg)
+// autocorrelation ... all-pole output for the NW = nStreams x c.nWin windows the stage kernel has laid out
+static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, hipStream_t st)
 {
     const int NW = v.nStreams * c.nWin, nGroups = (NW + 63) / 64;
-    V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
-    if (afterIngest) afterIngest(hookArg);
+    if (NW <= 0) return;
     // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
     if (nGroups * ((v.oVmax + 8) / 8 + (v.oSmax + 8) / 8) >= 1024) {
         const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
@@ -647,5 +774,22 @@ void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &
         default: v2_launch_iir_exact<48>(dim3(nGroups), st, g, c, d, v); break;
         }
     }
+}
+
+void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
+                  void (*afterIngest)(void *), void *hookArg)
+{
+    V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
+    if (afterIngest) afterIngest(hookArg);
+    v2_launch_middle(g, c, d, v, st);
     V2_LAUNCH(vp_k_v2_ola, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_out);
 }
+
+void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const VpV2MB &mb, const float *d_in, float *d_out,
+                         hipStream_t st)
+{
+    V2_LAUNCH(vp_k_v2_mb_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, mb, d_in);
+    v2_launch_middle(g, c, d, v, st);
+    V2_LAUNCH(vp_k_v2_mb_ola_emit, dim3(v.nStreams), dim3(256), (size_t)g.outSize * sizeof(double), g, c, d, v, mb, d_in, d_out);
+}
+
