@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
 // on the pair (i, p - i) at once -- each new value is old[i] - k * old[p - i], the same operands and operation as the
 // reference's pass over a copy.  A lane whose own order is smaller steps out of the remaining order steps (EXEC mask).
 template <int P>
-__global__ __launch_bounds__(64) void vp_k_v2_levinson_reg(VpGeom g, VpCall c, VpDev d, VpV2 v, int isS)
+__device__ __forceinline__ void v2_levinson_body(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
     const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
     const V2Win q = v2_window(c, d, v, w);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_levinson_reg(VpGeom g, VpCall c, V
 // Also leaves the slice's own sum of e^2 (in order) in EEp: VP_IIR_FAST takes the window energies as the sum of those (the
 // reference's single left-to-right sum -- vp_k_v2_energy -- stays the exact mode's), and then eVoice is not stored at all.
 template <int P>
-__global__ __launch_bounds__(64) void vp_k_v2_fir(VpGeom g, VpCall c, VpDev d, VpV2 v, int isS)
+__device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
     static_assert(P % 4 == 0 && P >= 4, "P multiple of 4");
     extern __shared__ double smem[];
@@ -342,7 +342,24 @@ __global__ __launch_bounds__(64) void vp_k_v2_fir(VpGeom g, VpCall c, VpDev d, V
     if (q.live) v.EEp[((size_t)wc * 2 + (isS ? 1 : 0)) * v.nSlices + blockIdx.y] = Ep;
 }
 
-// VP_IIR_FAST: window energies as the in-order sum of the slices' sums
+// The voice's and the side chain's coefficient / residual kernels are ONE launch each (blockIdx.y resp. blockIdx.z selects;
+// the side chain's orders are much smaller -- its own template parameter -- and its wavefronts fill in beside the voice's
+// instead of queueing behind them: 34 -> 24 us and 22 -> 18 us at 1024 streams).
+template <int PV, int PS>
+__global__ __launch_bounds__(64) void vp_k_v2_levinson2(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    if (blockIdx.y == 0) v2_levinson_body<PV>(g, c, d, v, 0);
+    else v2_levinson_body<PS>(g, c, d, v, 1);
+}
+template <int PV, int PS>
+__global__ __launch_bounds__(64) void vp_k_v2_fir2(VpGeom g, VpCall c, VpDev d, VpV2 v)
+{
+    if (blockIdx.z == 0) v2_fir_body<PV>(g, c, d, v, 0);
+    else v2_fir_body<PS>(g, c, d, v, 1);
+}
+
+// VP_IIR_FAST: window energies as the in-order sum of the slices' sums.  (A kernel of its own, 5 us: summed inside the
+// recursion kernel's gain prologue instead -- 160 dependent-latency loads per lane -- it cost that kernel 12 us.)
 __global__ __launch_bounds__(64) void vp_k_v2_energy_slices(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
     const int w = blockIdx.x * WAVE + threadIdx.x;
@@ -698,19 +715,25 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
 #define V2_LAUNCH(K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, st, __VA_ARGS__)
 #define V2_LAUNCH_ON(SX, K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, SX, __VA_ARGS__)
 
-template <int P> static void v2_launch_fir_t(dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
+// <PV, PS>: orders rounded up to the instantiated sizes (voice 8..48 in steps of 8; side chain 8, 16, 24, 32)
+template <int PV> static void v2_launch_lpc_fir_v(int ps, const dim3 &gl, const dim3 &gf, hipStream_t st, const VpGeom &g, const VpCall &c,
+                                                   const VpDev &d, const VpV2 &v)
 {
-    V2_LAUNCH(vp_k_v2_fir<P>, grid, dim3(64), (size_t)(P + V2_FIR_SLICE + 8) * 8, g, c, d, v, isS);
+#define V2_PAIR(PS) { V2_LAUNCH((vp_k_v2_levinson2<PV, PS>), gl, dim3(64), 0, g, c, d, v); \
+                      V2_LAUNCH((vp_k_v2_fir2<PV, PS>), gf, dim3(64), (size_t)((PV > PS ? PV : PS) + V2_FIR_SLICE + 8) * 8, g, c, d, v); }
+    if (ps <= 8) V2_PAIR(8) else if (ps <= 16) V2_PAIR(16) else if (ps <= 24) V2_PAIR(24) else V2_PAIR(32)
+#undef V2_PAIR
 }
-static void v2_launch_fir(int order, dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
+static void v2_launch_lpc_fir(int oV, int oS, int nGroups, int W, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v)
 {
-    switch ((order + 7) & ~7) {
-    case 8: v2_launch_fir_t<8>(grid, st, g, c, d, v, isS); break;
-    case 16: v2_launch_fir_t<16>(grid, st, g, c, d, v, isS); break;
-    case 24: v2_launch_fir_t<24>(grid, st, g, c, d, v, isS); break;
-    case 32: v2_launch_fir_t<32>(grid, st, g, c, d, v, isS); break;
-    case 40: v2_launch_fir_t<40>(grid, st, g, c, d, v, isS); break;
-    default: v2_launch_fir_t<48>(grid, st, g, c, d, v, isS); break;
+    const dim3 gl(nGroups, 2), gf(nGroups, (W + V2_FIR_SLICE - 1) / V2_FIR_SLICE, 2);
+    switch ((oV + 7) & ~7) {
+    case 8: v2_launch_lpc_fir_v<8>(oS, gl, gf, st, g, c, d, v); break;
+    case 16: v2_launch_lpc_fir_v<16>(oS, gl, gf, st, g, c, d, v); break;
+    case 24: v2_launch_lpc_fir_v<24>(oS, gl, gf, st, g, c, d, v); break;
+    case 32: v2_launch_lpc_fir_v<32>(oS, gl, gf, st, g, c, d, v); break;
+    case 40: v2_launch_lpc_fir_v<40>(oS, gl, gf, st, g, c, d, v); break;
+    default: v2_launch_lpc_fir_v<48>(oS, gl, gf, st, g, c, d, v); break;
     }
 }
 template <int P> static void v2_launch_iir_exact(dim3 grid, hipStream_t st, const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v)
@@ -738,23 +761,7 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
         const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
         V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
     }
-    auto lev = [&](hipStream_t sx, int top, int isS) {
-        switch ((top + 7) & ~7) {
-        case 8: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<8>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 16: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<16>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 24: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<24>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 32: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<32>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        case 40: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<40>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        default: V2_LAUNCH_ON(sx, vp_k_v2_levinson_reg<48>, dim3(nGroups), dim3(64), 0, g, c, d, v, isS); break;
-        }
-    };
-    // (the side chain's kernels, orders <= 30 and usually 5, first.  Running them beside the voice's on a second stream was
-    // tried: +-1 % at 1024 streams, +2 % at the configs[4] geometry, -7 % when the pitch kernel runs beside the pipeline too)
-    const dim3 gf(nGroups, (g.W + V2_FIR_SLICE - 1) / V2_FIR_SLICE);
-    lev(st, v.oSmax, 1);
-    lev(st, v.oVmax, 0);
-    v2_launch_fir(v.oSmax, gf, st, g, c, d, v, 1);
-    v2_launch_fir(v.oVmax, gf, st, g, c, d, v, 0);
+    v2_launch_lpc_fir(v.oVmax, v.oSmax, nGroups, g.W, st, g, c, d, v);
     if (c.iirFast) {
         V2_LAUNCH(vp_k_v2_energy_slices, dim3(nGroups), dim3(64), 0, g, c, d, v);
         // (two windows per row interleaved, NI = 2, was tried for few, long windows: 82 -> 133 us at the configs[4] geometry)
@@ -776,18 +783,20 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
     }
 }
 
-void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
+void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v_, const float *d_in, float *d_out, hipStream_t st,
                   void (*afterIngest)(void *), void *hookArg)
 {
+    const VpV2 &v = v_;
     V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
     if (afterIngest) afterIngest(hookArg);
     v2_launch_middle(g, c, d, v, st);
     V2_LAUNCH(vp_k_v2_ola, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_out);
 }
 
-void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const VpV2MB &mb, const float *d_in, float *d_out,
+void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v_, const VpV2MB &mb, const float *d_in, float *d_out,
                          hipStream_t st)
 {
+    const VpV2 &v = v_;
     V2_LAUNCH(vp_k_v2_mb_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, mb, d_in);
     v2_launch_middle(g, c, d, v, st);
     V2_LAUNCH(vp_k_v2_mb_ola_emit, dim3(v.nStreams), dim3(256), (size_t)g.outSize * sizeof(double), g, c, d, v, mb, d_in, d_out);
