@@ -589,3 +589,31 @@ def test_vocoder_multi_block_launch_equals_block_by_block(N, iir):
         _assert_equal(single, np.stack(ref), "single calls vs oracle")
         _assert_equal(run([B]), np.stack(ref), "one launch group vs oracle")
         _assert_equal(run([B], path="workgroup"), np.stack(ref), "workgroup path (block by block)")
+
+
+@pytest.mark.parametrize("order", [17, 24, 32, 33, 40, 47, 48])
+def test_fast_block_recursion_for_orders_17_to_48(order):
+    """FAST mode, pitch orders 17..48: the chunk's all-pole recursion runs as zero-state response of every 64-sample block
+    plus a 64 x order matrix applied to the previous outputs (iir_block_wave_hc).  Same tolerance as every FAST path
+    (RMS < 1e-4, north_star; in practice last-bit flips of the float32 cast), from a cold start, across frames, gate
+    closings and a block size that makes launches begin in the middle of a frame."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    import test_gpu_parity as T
+    S = 5
+    for N in (1024, 256):
+        B = 16 * (1024 // N)
+        x = T._streams(S, N * B)
+        x[1, 0] *= np.where((np.arange(N * B) // 5000) % 2 == 0, 1.0, 1e-6).astype(np.float32)     # gate closes and reopens
+        params = dict(lpcPitch=order, vocBool=0)
+        ref = T._oracle_run(x, N, params)
+        p = BatchVocoderProcessor(**params)
+        p.prepareToPlay(T.FS, N, S)
+        p.set_iir_mode("fast")
+        p.set_yin_mode("xcorr")
+        got = p.run(x)
+        err = got.astype(np.float64) - ref
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.isfinite(got).all()
+        assert np.sqrt((err ** 2).mean()) < 1e-4
+        assert np.abs(err).max() <= 4e-7 * scale, (order, N, np.abs(err).max(), scale)
+        assert np.abs(ref).max() > 0.01, "vacuous comparison"

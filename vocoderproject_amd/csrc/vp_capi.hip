@@ -564,7 +564,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.outEFrame, (size_t)S * F));
     RC(dev_alloc(h, &d.yFrame, (size_t)S * F));
     RC(dev_alloc(h, &d.EeArr, (size_t)S * 20));
-    RC(dev_alloc(h, &d.hImp, (size_t)S * 64));
+    RC(dev_alloc(h, &d.hImp, (size_t)S * 128));
     RC(dev_alloc(h, &d.ub, (size_t)5));
     RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S));        // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks
     RC(dev_upload(h, &d.vocWin, vocWin));

@@ -84,7 +84,7 @@ struct VpDev {
     VpPitchState *pitch;
     double *eFrame, *outEFrame, *yFrame;
     double *EeArr;
-    double *hImp;            // [S][64] impulse response of the in-flight pitch frame's 1/A(z) (block-form IIR)
+    double *hImp;            // [S][128] impulse response of the in-flight pitch frame's 1/A(z) (block-form IIR)
     const double *vocWin;    // [W]  anWindow == stWindow ("sine", VocoderProcess.cpp:125-129)
     const double *pitchStWin;// [F]
     const double *hannTab;   // hann(2T+1) for T = 1..tauMax, concatenated
@@ -109,10 +109,10 @@ struct VpDev {
 
 // Pitch kernel, LDS: length (doubles) of the yinTemp and running-sum regions.  They double as scratch once the pitch is
 // picked -- the PSOLA grain table (2 x VP_MARKS doubles + 5 x VP_MARKS ints from dY[0]), the exact recursion's history
-// (cum[0 .. order)), the block-form IIR's impulse response and input (cum[128 .. 320)) -- so at low sample rates, where
+// (cum[0 .. order)), the block-form IIR's impulse response and input (cum[128 .. 448)) -- so at low sample rates, where
 // tauMax + 1 is smaller than that scratch, the regions are sized for the scratch instead.
 VP_HD static inline int vp_dy_len(int tauMax) { const int need = 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2; return tauMax + 1 > need ? tauMax + 1 : need; }
-VP_HD static inline int vp_cum_len(int tauMax) { return tauMax + 1 > 320 ? tauMax + 1 : 320; }
+VP_HD static inline int vp_cum_len(int tauMax) { return tauMax + 1 > 448 ? tauMax + 1 : 448; }
 
 // doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
 VP_HD static inline size_t voc_wave_doubles(int W)

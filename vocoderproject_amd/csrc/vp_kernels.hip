@@ -812,6 +812,80 @@ __device__ __forceinline__ void iir_block_wave_regs(const lds_f64 *x, lds_f64 *y
         if (bn < n) { X0 = x[bn + m]; X1 = x[bn + 16 + m]; X2 = x[bn + 32 + m]; X3 = x[bn + 48 + m]; }
     }
 }
+
+// The block form for orders 17..48 (whole 64-sample blocks, ONE full wavefront), with the recursion between the blocks
+// reduced to what really is serial.  By linearity a block's outputs are
+//     y[b + i] = z[b + i] + sum_{k=1..order} Hc[i][k] * y[b - k],        z = T(h) (g x)   (zero-state response),
+// where column k of Hc is the block's response to a unit in history slot k.  Phase 1 computes z for ALL blocks of the chunk
+// (no dependence between them: 64 DPP terms per block, taps in registers as above).  Phase 2 walks the blocks with the
+// lane's row Hc[lane][1..48] in registers and the last 48 outputs in three row-broadcast registers: `order` DPP terms and
+// one LDS round trip per 64 samples (the LDS form above: 112 terms with two LDS reads each, 2.3 us per block at order 48).
+// Hc comes from the impulse response without any sum over taps:  Hc[i][1] = h[i+1],  Hc[i][k+1] = Hc[i+1][k] + a[k] h[i+1]
+// (shift the carry-in sequence u_k[j] = -a[j+k] left by one), i.e. 47 steps of "lane i takes lane i+1's value" on h[0..111]:
+// hpad holds 64 zeros, then h[0..127].  nh0 = valid outputs before y[0].  Rounding differs from the other FAST forms only
+// in how the same sums are grouped.
+__device__ __forceinline__ void iir_block_wave_hc(const lds_f64 *x, lds_f64 *y, int n, const lds_f64 *aL, int order_, int nh0,
+                                                  const lds_f64 *hpad, double gmul)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+    {
+        double H[64];
+#pragma unroll
+        for (int j = 0; j < 64; j++) H[j] = hpad[WAVE + lane - j];            // h[lane - j], 0 for j > lane
+        for (int b = 0; b < n; b += WAVE) {
+            double X0 = gmul * x[b + m], X1 = gmul * x[b + 16 + m], X2 = gmul * x[b + 32 + m], X3 = gmul * x[b + 48 + m];
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            asm volatile("s_nop 1" : "+v"(X0), "+v"(X1), "+v"(X2), "+v"(X3));     // VALU write -> DPP read
+            VP_BI_ROW(X0, 0)
+            VP_BI_ROW(X1, 1)
+            VP_BI_ROW(X2, 2)
+            VP_BI_ROW(X3, 3)
+            y[b + lane] = (acc0 + acc1) + (acc2 + acc3);
+        }
+    }
+    double R[48];
+    {
+        const lds_f64 *h = hpad + WAVE;
+        const double h0 = h[lane + 1], h1 = (lane + 65 < 128) ? h[lane + 65] : 0.0;   // h[i + 1] for i = lane, lane + 64
+        double c0 = h0, c1 = h1;
+        R[0] = c0;
+#pragma unroll
+        for (int k = 1; k < 48; k++) {
+            const double ak = (k <= order) ? aL[k] : 0.0;
+            const double up = bcast_f64(c1, 0);
+            double n0 = wave_shl1_f64(c0);
+            const double n1 = wave_shl1_f64(c1);
+            if (lane == 63) n0 = up;
+            c0 = __builtin_fma(ak, h0, n0);
+            c1 = __builtin_fma(ak, h1, n1);
+            R[k] = c0;
+        }
+    }
+    for (int b = 0; b < n; b += WAVE) {
+        // Yq[lane] = y[b - 16 (4 - q) + (lane & 15)]: history slot k = 16 (4 - q) - m sits in lane 16 (4 - q) - k of the row.
+        // Slots beyond the order, or before the frame's first sample, read as zero (never from LDS: a zero coefficient does
+        // not neutralise a NaN somebody else left there).
+        const int kHave = (b == 0) ? min(order, nh0) : order;
+        double Y3 = 0.0, Y2 = 0.0, Y1 = 0.0;
+        if (16 - m <= kHave) Y3 = y[b - 16 + m];
+        if (32 - m <= kHave) Y2 = y[b - 32 + m];
+        if (48 - m <= kHave) Y1 = y[b - 48 + m];
+        const double z = y[b + lane];
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        asm volatile("s_nop 1" : "+v"(Y1), "+v"(Y2), "+v"(Y3));
+#define VP_HC_ROW(YQ, K0) \
+        VP_BI_T(acc0, YQ, R[K0 + 0], 15);  VP_BI_T(acc1, YQ, R[K0 + 1], 14);  VP_BI_T(acc2, YQ, R[K0 + 2], 13);  VP_BI_T(acc3, YQ, R[K0 + 3], 12);  \
+        VP_BI_T(acc0, YQ, R[K0 + 4], 11);  VP_BI_T(acc1, YQ, R[K0 + 5], 10);  VP_BI_T(acc2, YQ, R[K0 + 6], 9);   VP_BI_T(acc3, YQ, R[K0 + 7], 8);   \
+        VP_BI_T(acc0, YQ, R[K0 + 8], 7);   VP_BI_T(acc1, YQ, R[K0 + 9], 6);   VP_BI_T(acc2, YQ, R[K0 + 10], 5);  VP_BI_T(acc3, YQ, R[K0 + 11], 4);  \
+        VP_BI_T(acc0, YQ, R[K0 + 12], 3);  VP_BI_T(acc1, YQ, R[K0 + 13], 2);  VP_BI_T(acc2, YQ, R[K0 + 14], 1);  VP_BI_T(acc3, YQ, R[K0 + 15], 0);
+        VP_HC_ROW(Y3, 0)
+        if (order > 16) { VP_HC_ROW(Y2, 16) }
+        if (order > 32) { VP_HC_ROW(Y1, 32) }
+#undef VP_HC_ROW
+        y[b + lane] = z + ((acc0 + acc1) + (acc2 + acc3));
+    }
+}
 #undef VP_BI_ROW
 
 // ------------------------------------------------------------------------------------------------
@@ -1611,6 +1685,33 @@ __device__ __forceinline__ void iir_exact_row16(XP x, YP y, int n, AP aL, int or
     }
 }
 
+// Which block form runs the chunk's recursion (FAST mode, whole 64-sample blocks): orders up to 16 the register form, 17..48
+// iir_block_wave_hc (it needs 128 samples of the impulse response instead of 64), else the LDS form.  The register-light
+// builds keep the LDS form (the other two hold 64 taps in registers).
+template <bool LITE, bool COMMON>
+__device__ __forceinline__ bool pitch_iir_hc(const VpGeom &g)
+{
+#ifdef VP_DIAG_NO_HC_IIR
+    return false;
+#else
+    return !LITE && !COMMON && g.orderPitch > 16 && g.orderPitch <= 48;
+#endif
+}
+// LDS scratch of the block forms inside cum[]: 64 zeros, the impulse response (up to 128 samples), 128 doubles of input
+#define VP_HPAD_OFF 128
+#define VP_XP_OFF 320
+template <bool LITE, bool COMMON>
+__device__ __forceinline__ void pitch_impulse_response(const VpGeom &g, const PitchLds &L, const lds_f64 *a)
+{
+    lds_f64 *hpad = L.cum + VP_HPAD_OFF, *xp = L.cum + VP_XP_OFF;
+    const int lane = threadIdx.x & 63;
+    const int nh = pitch_iir_hc<LITE, COMMON>(g) ? 2 * WAVE : WAVE;
+    hpad[lane] = 0.0;
+    xp[lane] = (lane == 0) ? 1.0 : 0.0;
+    if (nh > WAVE) xp[WAVE + lane] = 0.0;
+    iir_fast_wave(xp, hpad + WAVE, nh, a, g.orderPitch, (const lds_f64 *)nullptr, 1.0);
+}
+
 // PitchProcess::filterIIR (PitchProcess.cpp:307-322): serial recursion.  Called by ONE wavefront;
 // all 64 lanes run the same chain redundantly (full EXEC mask: see the vocoder's note), identical stores.
 template <bool LITE, bool FAST, bool COMMON>
@@ -1619,12 +1720,9 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
     if (FAST && (COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE))) {
         // block form; the impulse response of the frame's 1/A(z) lives in cum[128..256) (64 zeros in front)
         const int shift = nChunk * g.C, order = g.orderPitch;
-        lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
+        lds_f64 *hpad = L.cum + VP_HPAD_OFF, *xp = L.cum + VP_XP_OFF;
         if (!hValid) {                                   // normally precomputed (Start, wave 7) or reloaded (kernel start)
-            const int lane = threadIdx.x & 63;
-            hpad[lane] = 0.0;
-            xp[lane] = (lane == 0) ? 1.0 : 0.0;
-            iir_fast_wave(xp, hpad + WAVE, WAVE, (const lds_f64 *)L.st->a, order, (const lds_f64 *)nullptr, 1.0);
+            pitch_impulse_response<LITE, COMMON>(g, L, (const lds_f64 *)L.st->a);
             hValid = true;
         }
 #ifdef VP_DIAG_NO_REGS_IIR
@@ -1633,6 +1731,8 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
         if (!LITE && (COMMON || order <= 16))
 #endif
             iir_block_wave_regs((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, shift > 0, hpad);
+        else if (pitch_iir_hc<LITE, COMMON>(g))
+            iir_block_wave_hc((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, 1.0);
         else
             iir_block_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, xp, 1.0);
         return;
@@ -2243,11 +2343,7 @@ __device__ __forceinline__ int pitch_chunk_start_pre(const VpGeom &g, const VpCa
         if (COMMON || (g.C & 63) == 0) {
             // ... the impulse response of the new 1/A(z) for the block-form IIR (cum[] is dead after
             // the normalisation; layout as in pitch_iir_wave)
-            lds_f64 *hpad = L.cum + 128, *xp = L.cum + 256;
-            const int lane = tid & 63;
-            hpad[lane] = 0.0;
-            xp[lane] = (lane == 0) ? 1.0 : 0.0;
-            iir_fast_wave(xp, hpad + WAVE, WAVE, (const lds_f64 *)L.aPrev, g.orderPitch, (const lds_f64 *)nullptr, 1.0);
+            pitch_impulse_response<LITE, COMMON>(g, L, (const lds_f64 *)L.aPrev);
         }
     }
     __syncthreads();
@@ -2362,7 +2458,8 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         for (int i = done + tid; i < g.F; i += nt) L.oE[i] = go[i];
         for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) L.yF[i] = gy[i];
         if (COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE)) {   // the frame's impulse response (block-form IIR)
-            if (tid < WAVE) { L.cum[128 + tid] = 0.0; L.cum[128 + WAVE + tid] = d.hImp[(size_t)s * WAVE + tid]; }
+            if (tid < WAVE) L.cum[VP_HPAD_OFF + tid] = 0.0;
+            if (tid < (pitch_iir_hc<LITE, COMMON>(g) ? 2 * WAVE : WAVE)) L.cum[VP_HPAD_OFF + WAVE + tid] = d.hImp[(size_t)s * 2 * WAVE + tid];
         }
     }
     if (nSteps > 0) load_xs(0, tid);
@@ -2466,7 +2563,8 @@ __device__ __forceinline__ void pitch_kernel_body(const VpGeom &g, const VpCall 
         for (int i = tid; i < g.eLen; i += nt) ge[i] = L.eF[i];
         for (int i = done + tid; i < g.F; i += nt) go[i] = L.oE[i];
         for (int i = max(0, done - g.orderPitch) + tid; i < done; i += nt) gy[i] = L.yF[i];
-        if ((COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE)) && tid < WAVE) d.hImp[(size_t)s * WAVE + tid] = L.cum[128 + WAVE + tid];
+        if ((COMMON || ((g.C & 63) == 0 && g.orderPitch < WAVE)) && tid < (pitch_iir_hc<LITE, COMMON>(g) ? 2 * WAVE : WAVE))
+            d.hImp[(size_t)s * 2 * WAVE + tid] = L.cum[VP_HPAD_OFF + WAVE + tid];
     }
     STAMP(d, 11);
     if (c.fuseEmit) {
