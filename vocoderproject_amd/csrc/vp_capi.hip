@@ -511,7 +511,12 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     {
         const int stepsMax = (N + g.C - 1) / g.C;
         // batches that can use the two-workgroups-per-CU build keep the frame within half a CU's LDS
-        const size_t budget = std::min<size_t>(ldsMax, (g.S > 256 ? 80 : 112) * 1024);
+        size_t budget = std::min<size_t>(ldsMax, (g.S > 256 ? 80 : 112) * 1024);
+        {   // a frame that is beyond that budget even with one step staged has a CU to itself whatever is done here: use it
+            VpGeom t = g;
+            t.xsSteps = 1;
+            if (vp_pitch_lds_bytes(t) > budget) budget = ldsMax;
+        }
         for (int k = stepsMax; k >= 1; k--) {
             VpGeom t = g;
             t.xsSteps = k;
