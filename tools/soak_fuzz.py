@@ -3,6 +3,7 @@
 (GPU box only; prints a summary line, exits non-zero on the first mismatch).
 
     python tools/soak_fuzz.py [first_seed] [count]
+    VP_SOAK_LITE=1 / VP_SOAK_R2=1 / VP_SOAK_FAST=1 select the large-batch, round-2 or FAST-mode-against-exact cases instead
 """
 import os
 import sys
@@ -98,6 +99,7 @@ def main():
     ok = skipped = 0
     for seed in range(first, first + count):
         fns = (lite_case,) if os.environ.get("VP_SOAK_LITE") else (round2_case,) if os.environ.get("VP_SOAK_R2") else \
+              (T.test_randomised_configurations_fast_modes_against_exact,) if os.environ.get("VP_SOAK_FAST") else \
               (T.test_randomised_configurations_bit_exact, T.test_randomised_configurations_with_extensions_bit_exact)
         for fn in fns:
             try:

@@ -1067,7 +1067,21 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         // EXEC mask it is slower and, worse, chains in different waves then serialise (measured,
         // tools/ubench_iir.hip modes 1 vs 3).  Spare lanes redo the last window (identical stores).
         if (LITE || c.iirFast) {
-            if (active) iir_fast_wave(A, B, W, aV, oV, (const lds_f64 *)nullptr, gArr[wave]);   // wave per window, lanes over taps
+            if (active) {
+#ifndef VP_DIAG_NO_HC_IIR
+                if (!LITE && (W & 63) == 0 && W >= 5 * WAVE && oV > 16 && oV <= 48) {
+                    // block form (iir_block_wave_hc): the window's impulse response (128 samples of the serial form below)
+                    // instead of all W of them, then 64 outputs at a time; scratch in D (eVoice: only its energy was needed)
+                    lds_f64 *hpad = D, *xp = D + 3 * WAVE;
+                    hpad[lane] = 0.0;
+                    xp[lane] = (lane == 0) ? 1.0 : 0.0;
+                    xp[WAVE + lane] = 0.0;
+                    iir_fast_wave(xp, hpad + WAVE, 2 * WAVE, aV, oV, (const lds_f64 *)nullptr, 1.0);
+                    iir_block_wave_hc((const lds_f64 *)A, B, W, (const lds_f64 *)aV, oV, 0, hpad, gArr[wave]);
+                } else
+#endif
+                iir_fast_wave(A, B, W, aV, oV, (const lds_f64 *)nullptr, gArr[wave]);   // wave per window, lanes over taps
+            }
         } else if (waveHw == 0) {
             const int wj = min(lane, nAct - 1);
             lds_f64 *wb = gArr + 8 + (size_t)wj * voc_wave_doubles(W);        // window `wj` of this round
