@@ -443,6 +443,49 @@ __device__ __noinline__ bool levinson_scalar(const lds_f64 *r, lds_f64 *a, int o
     return false;
 }
 
+// The same register-resident recursion with one WINDOW per lane (r, a: the lane's own vectors; the order is wave-uniform):
+// the workgroup vocoder's round of up to eight windows on ONE wavefront instead of eight wavefronts that each run it 64 times
+// over (they share four SIMDs and an LDS pipe: 27 us per round at order 40 for the wave-distributed form).  A lane whose
+// r[0] is below eps writes the unit vector (LPC.cpp:110-114) and steps out.
+template <int P>
+__device__ __noinline__ void levinson_lanes(const lds_f64 *r, lds_f64 *a, int order_, int aLen, double eps)
+{
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+    double rr[P + 1], aa[P + 1];
+#pragma unroll
+    for (int k = 0; k <= P; k++) { rr[k] = (k <= order) ? r[k] : 0.0; aa[k] = 0.0; }
+    const double r0 = rr[0];
+    if (fabs(r0) < eps) {
+        for (int i = 0; i < aLen; i++) a[i] = (i == 0) ? 1.0 : 0.0;
+        return;
+    }
+    aa[0] = 1.0;
+    aa[1] = rr[1] / r0;
+#pragma unroll
+    for (int p = 2; p <= P; p++) {
+        if (p <= order) {                          // wave-uniform
+            double rho_a = 0.0, r_a = 0.0;
+#pragma unroll
+            for (int i = 1; i < p; i++) {          // :120-128
+                rho_a += rr[p - i] * aa[i];
+                r_a += rr[i] * aa[i];
+            }
+            const double k = (rr[p] - rho_a) / (r0 - r_a);
+#pragma unroll
+            for (int i = 1; 2 * i <= p; i++) {     // a[i] = aPrev[i] - k aPrev[p-i], both ends of the pair
+                const double ai = aa[i], aj = aa[p - i];
+                aa[i] = ai - k * aj;
+                if (2 * i != p) aa[p - i] = aj - k * ai;
+            }
+            aa[p] = k;
+        }
+    }
+    a[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k <= P; k++)
+        if (k <= order) a[k] = aa[k] * -1.;                                  // :145-146
+}
+
 // Left-to-right sums of e[i]^2 for two arrays at once (VocoderProcess.cpp:250), every lane of the
 // calling wavefront redundantly: eight entries are read ahead per trip so that only the two
 // (interleaved) chains of dependent adds remain.
@@ -989,6 +1032,25 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         }
         __syncthreads();
         STAMP(d, 17);
+#ifdef VP_DIAG_NO_LANES_LEV
+        const bool lanesLev = false;
+#else
+        const bool lanesLev = !LITE && nRoles == 1 && nWaves >= 2 && W >= 128 && oV > 16 && oV <= 48;
+#endif
+        if (lanesLev) {
+            // the voice's recursions of the whole round on wave 0, one window per lane (spare lanes redo the last one); the
+            // carrier's (order <= 30, wave-distributed) on the windows' own wavefronts meanwhile, wave 0's window by wave 1
+            if (waveHw == 0) {
+                lds_f64 *wb = gArr + 8 + (size_t)min(lane, nAct - 1) * voc_wave_doubles(W);
+                levinson_lanes<48>((const lds_f64 *)(wb + 4 * (size_t)W), wb + 4 * (size_t)W + (VP_ORDER_MAX + 1), oV, VP_ORDER_MAX + 1, g.levEps);
+            } else {
+                if (activeW) levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, D);
+                if (waveHw == 1) {
+                    lds_f64 *wb = gArr + 8, *rS0 = wb + 4 * (size_t)W + 2 * (VP_ORDER_MAX + 1);
+                    levinson_wave(rS0, rS0 + (VP_ORDER_MAX_SYNTH + 1), oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, wb + 3 * (size_t)W);
+                }
+            }
+        } else
         if (activeW && role < 2) {                       // whole wavefront, coefficient vector over the lanes
             // eVoice is not written yet: scratch (128 doubles each; the carrier's recursion runs beside the voice's on
             // the window's second wavefront when it has one)
