@@ -943,6 +943,57 @@ __device__ __forceinline__ void iir_block_wave_hc(const lds_f64 *x, lds_f64 *y, 
 //   D  [W] f64   eVoice (only its energy is used)
 //   r/a for voice (101 each) and synth (31 each)
 
+// biaisedAutoCorr of the vocoder (LPC.cpp:44-97), TWO adjacent lags per lane (m and m + 1, m even): r[m] = sum_n
+// ((xw[n] * x[n+m]) * w[n+m]), n ascending, each product rounded as the reference rounds it.  The one-lag form pays three LDS
+// reads per element and lag, and the eight wavefronts of a round are bound by the LDS pipe (25 us per round at 512-sample
+// windows); here the lane's raw samples and window values slide past xw[n] -- one new value of each serves two lags -- and
+// the caller packs two windows into a wavefront, so the round issues a quarter of the LDS instructions.
+// xw: the window's x * anWindow (f64), xf: its raw samples + m (f32), wm: anWindow + m; all 8-byte (xf) / 16-byte aligned.
+// Requests run two trips ahead, unconditionally (up to 16 elements past the lane's count: inside the LDS allocation).
+__device__ __forceinline__ void voc_autocorr2(const lds_f64 *xw, const lds_f32 *xf, const lds_f64 *wm, int cntA, double &sA, double &sB)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) d2 lds_d2;
+    typedef __attribute__((address_space(3))) f2 lds_f2;
+    const int cntB = cntA - 1, c8 = max(cntB, 0) & ~7;
+    double w0 = wm[0], w1 = wm[1], f0 = (double)xf[0], f1 = (double)xf[1];
+    d2 u0[4], q0[4], u1[4], q1[4];
+    f2 x0[4], x1[4];
+#define VP_V2LOAD(U, Q, X, I) _Pragma("unroll") for (int u = 0; u < 4; u++) { \
+        U[u] = *(const lds_d2 *)(xw + (I) + 2 * u); Q[u] = *(const lds_d2 *)(wm + (I) + 2 + 2 * u); X[u] = *(const lds_f2 *)(xf + (I) + 2 + 2 * u); }
+#define VP_V2COMP(U, Q, X) { \
+        const double g0 = (double)X[0].x, g1 = (double)X[0].y, g2 = (double)X[1].x, g3 = (double)X[1].y, \
+                     g4 = (double)X[2].x, g5 = (double)X[2].y, g6 = (double)X[3].x, g7 = (double)X[3].y; \
+        double pa[8], pb[8]; \
+        pa[0] = U[0].x * f0; pb[0] = U[0].x * f1; pa[1] = U[0].y * f1; pb[1] = U[0].y * g0; \
+        pa[2] = U[1].x * g0; pb[2] = U[1].x * g1; pa[3] = U[1].y * g1; pb[3] = U[1].y * g2; \
+        pa[4] = U[2].x * g2; pb[4] = U[2].x * g3; pa[5] = U[2].y * g3; pb[5] = U[2].y * g4; \
+        pa[6] = U[3].x * g4; pb[6] = U[3].x * g5; pa[7] = U[3].y * g5; pb[7] = U[3].y * g6; \
+        pa[0] *= w0;     pb[0] *= w1;     pa[1] *= w1;     pb[1] *= Q[0].x; \
+        pa[2] *= Q[0].x; pb[2] *= Q[0].y; pa[3] *= Q[0].y; pb[3] *= Q[1].x; \
+        pa[4] *= Q[1].x; pb[4] *= Q[1].y; pa[5] *= Q[1].y; pb[5] *= Q[2].x; \
+        pa[6] *= Q[2].x; pb[6] *= Q[2].y; pa[7] *= Q[2].y; pb[7] *= Q[3].x; \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { sA += pa[u]; sB += pb[u]; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        f0 = g6; f1 = g7; w0 = Q[3].x; w1 = Q[3].y; }
+    VP_V2LOAD(u0, q0, x0, 0)
+    VP_V2LOAD(u1, q1, x1, 8)
+    int n = 0;
+    for (; n + 16 <= c8; n += 16) {
+        VP_V2COMP(u0, q0, x0)
+        VP_V2LOAD(u0, q0, x0, n + 16)
+        VP_V2COMP(u1, q1, x1)
+        VP_V2LOAD(u1, q1, x1, n + 24)
+    }
+    if (n < c8) { VP_V2COMP(u0, q0, x0) }
+#undef VP_V2LOAD
+#undef VP_V2COMP
+    for (int i = c8; i < cntA; i++) sA += (xw[i] * (double)xf[i]) * wm[i];
+    for (int i = c8; i < cntB; i++) sB += (xw[i] * (double)xf[i + 1]) * wm[i + 1];
+}
+
 // LITE: the build for two workgroups per CU (<= 128 VGPRs, FAST IIR only -- the register-resident exact recursion is
 // compiled out; the host never launches it in exact mode).
 template <bool LITE>
@@ -1000,6 +1051,28 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 
         // biaisedAutoCorr (LPC.cpp:44-97) for voice lags 0..oV and synth lags 0..oS: one lane per
         // lag, each lag its own left-to-right sum over n.
+        // (two lags per lane, two windows per wavefront when all of a window's lag pairs fit 32 lanes: voc_autocorr2)
+        const int nPV = (oV >> 1) + 1, nPS = (oS >> 1) + 1;
+#ifdef VP_DIAG_NO_VOC_AC2
+        const bool ac2 = false;
+#else
+        const bool ac2 = !LITE && nRoles == 1 && nPV + nPS <= 32 && (W & 1) == 0 && W > oV + 2 && W > oS + 2;
+#endif
+        if (ac2) {
+            const int half = lane >> 5, l = lane & 31;
+            if (2 * waveHw < nAct) {
+                const int wj0 = 2 * waveHw + half, wj = min(wj0, nAct - 1);
+                lds_f64 *wb = gArr + 8 + (size_t)wj * voc_wave_doubles(W);
+                const bool isV = l < nPV;
+                const int m = 2 * (isV ? l : min(l - nPV, nPS - 1)), ord = isV ? oV : oS;
+                double sA = 0.0, sB = 0.0;
+                voc_autocorr2((const lds_f64 *)(wb + (isV ? 1 : 2) * (size_t)W), (const lds_f32 *)wb + (isV ? 0 : W) + m, (const lds_f64 *)win + m, W - m, sA, sB);
+                sA /= (double)W;
+                sB /= (double)W;
+                lds_f64 *rdst = wb + 4 * (size_t)W + (isV ? 0 : 2 * (VP_ORDER_MAX + 1));
+                if (wj0 < nAct && l < nPV + nPS) { rdst[m] = sA; if (m + 1 <= ord) rdst[m + 1] = sB; }
+            }
+        } else
         if (activeW) {
             const int nLags = oV + 1 + oS + 1;
             // whole wavefronts (spare lanes redo the last lag, no store): partial-EXEC loops are slow
