@@ -994,6 +994,37 @@ __device__ __forceinline__ void voc_autocorr2(const lds_f64 *xw, const lds_f32 *
     for (int i = c8; i < cntB; i++) sB += (xw[i] * (double)xf[i + 1]) * wm[i + 1];
 }
 
+// E = sum e[i]^2 left to right (VocoderProcess.cpp:250) with one WINDOW per lane (e: the lane's own residual, 16-byte aligned):
+// the round's eight sums on one wavefront instead of eight wavefronts that each chain 2 W dependent adds on shared SIMDs.
+// Eight entries per trip, requested two trips ahead (unconditionally: up to 16 entries past n, inside the LDS allocation).
+__device__ __forceinline__ double energy_lanes(const lds_f64 *e, int n)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) d2 lds_d2;
+    double E = 0.0;
+    const int n8 = n & ~7;
+    d2 a0[4], a1[4];
+#define VP_ELLOAD(A, I) _Pragma("unroll") for (int u = 0; u < 4; u++) A[u] = *(const lds_d2 *)(e + (I) + 2 * u);
+#define VP_ELCOMP(A) { double s_[8]; _Pragma("unroll") for (int u = 0; u < 4; u++) { s_[2 * u] = A[u].x * A[u].x; s_[2 * u + 1] = A[u].y * A[u].y; } \
+        __builtin_amdgcn_sched_barrier(0); \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) E += s_[u]; \
+        __builtin_amdgcn_sched_barrier(0); }
+    VP_ELLOAD(a0, 0)
+    VP_ELLOAD(a1, 8)
+    int i = 0;
+    for (; i + 16 <= n8; i += 16) {
+        VP_ELCOMP(a0)
+        VP_ELLOAD(a0, i + 16)
+        VP_ELCOMP(a1)
+        VP_ELLOAD(a1, i + 24)
+    }
+    if (i < n8) { VP_ELCOMP(a0) }
+#undef VP_ELLOAD
+#undef VP_ELCOMP
+    for (int k = n8; k < n; k++) E += e[k] * e[k];
+    return E;
+}
+
 // LITE: the build for two workgroups per CU (<= 128 VGPRs, FAST IIR only -- the register-resident exact recursion is
 // compiled out; the host never launches it in exact mode).
 template <bool LITE>
@@ -1159,6 +1190,18 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
         }
         __syncthreads();
         STAMP(d, 19);
+#ifdef VP_DIAG_NO_LANES_ENERGY
+        const bool lanesE = false;
+#else
+        const bool lanesE = !LITE && nRoles == 1 && nWaves >= 2 && (W & 1) == 0;
+#endif
+        if (lanesE) {                                    // wave 0: the round's eVoice sums, wave 1: its eSynth sums, a window per lane
+            if (waveHw < 2) {
+                const lds_f64 *wb = gArr + 8 + (size_t)min(lane, nAct - 1) * voc_wave_doubles(W);
+                const double E = energy_lanes(wb + (waveHw == 0 ? 3 * (size_t)W : 0), W);
+                if (lane < nAct) roundE[8 * waveHw + lane] = E;
+            }
+        } else
         if (activeW && role < 2) {                       // E += e[i]*e[i], left to right (:250)
             if (nRoles == 1) {
                 double Ev, Es;
