@@ -7,6 +7,7 @@
 # profiles/<tag>_counters.json (what bench.py reads) and copies the kernel-stats csvs.
 tag=${1:-r02}
 out=$PWD/gpurun_out/ctr_$tag
+rm -rf $out          # (a tree merged from several runs would mix their files)
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
@@ -28,3 +29,6 @@ sel=${2:-all}
 [ $sel = all -o $sel = cfg5 ] && run cfg5_both_s512 --cfg5 --mode both --streams 512
 [ $sel = all -o $sel = cfg2x ] && run cfg2_pitch_s256_exact --iir exact
 python3 tools/summarize_counters.py $out $tag
+# the summary as this box computed it travels back with gpurun_out/ (copy gpurun_out/ctr_<tag>/_profiles/* into profiles/)
+mkdir -p $out/_profiles
+cp profiles/${tag}_counters.json profiles/${tag}_*_kernel_stats.csv profiles/${tag}_*_bench_under_rocprof.json $out/_profiles/

@@ -15,6 +15,7 @@ fi
 run --mode voc --streams 256
 run --mode voc --streams 256 --iir exact
 run --mode both --streams 256
+run --mode pitch --streams 1024
 run --mode both --streams 1024          # configs[3]: 8192 streams = 1024 per GPU
 run --mode both --streams 1024 --iir exact
 run --mode both --streams 1024 --voc-path workgroup
