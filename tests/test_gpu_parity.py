@@ -1061,8 +1061,9 @@ def test_randomised_configurations_with_extensions_bit_exact(seed):
 @pytest.mark.parametrize("params,N", [(dict(), 1024), (dict(pitchBool=0, lpcVoice=64, lpcSynth=30), 1024), (dict(pitchBool=0), 300)])
 def test_register_light_vocoder_for_large_batches(params, N):
     """Above 256 streams in FAST IIR mode the host launches vp_k_vocoder_lite: half the window slots, two wavefronts per
-    slot, two workgroups per CU.  Same arithmetic as the regular FAST vocoder: the streams must come out bit-identical
-    to what a small batch (regular build) gives, and within the stated tolerance of the oracle."""
+    slot, two workgroups per CU.  Same filters as the regular FAST vocoder (whose recursion and Levinson-Durbin take other,
+    register-heavier forms since round 2: rounding-level differences): the streams must come out as a small batch (regular
+    build) gives them up to last-bit flips of the float32 cast, and within the stated tolerance of the oracle."""
     from vocoderproject_amd import BatchVocoderProcessor
     S, B = 300, 8
     x = _streams(S, N * B)
@@ -1079,7 +1080,8 @@ def test_register_light_vocoder_for_large_batches(params, N):
     big = run(x)
     pick = [0, 7, 255, 256, 299]
     small = run(np.ascontiguousarray(x[pick]))                       # <= 256 streams: vp_k_vocoder
-    _assert_equal(big[pick], small, "lite vs regular FAST vocoder")
+    dlt = np.abs(big[pick].astype(np.float64) - small)
+    assert dlt.max() <= 4e-7 * max(1.0, float(np.abs(small).max())) and (big[pick] != small).mean() < 0.02, "lite vs regular FAST vocoder"
     ref = _oracle_run(x[pick], N, params)
     err = big[pick].astype(np.float64) - ref
     assert np.sqrt((err ** 2).mean()) < RMS_TOL

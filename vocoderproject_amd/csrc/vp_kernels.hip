@@ -11,6 +11,7 @@
 //   * across vocoder windows of a block (one wavefront per window).
 // Citations are file:line relative to /root/reference/Source/.
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <limits.h>
 
 #include "vp_common.h"
@@ -926,6 +927,70 @@ __device__ __forceinline__ void iir_block_wave_hc(const lds_f64 *x, lds_f64 *y, 
         if (order > 16) { VP_HC_ROW(Y2, 16) }
         if (order > 32) { VP_HC_ROW(Y1, 32) }
 #undef VP_HC_ROW
+        y[b + lane] = z + ((acc0 + acc1) + (acc2 + acc3));
+    }
+}
+
+// The same decomposition for orders up to 16 in the register-light builds (two workgroups per CU, 128 VGPRs: the 64 taps of
+// iir_block_wave_regs do not fit, and the LDS form spends 35 us per 1024 samples on its reads): the zero-state responses in
+// four passes of 16 taps each, the history matrix row (16 entries) summed directly from the 64-sample impulse response --
+// Hc[i][k] = -sum_{j=0..16-k} h[i-j] a[j+k], the coefficients through the row broadcast -- and 16 DPP terms per block in
+// the serial pass.
+template <int M>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double rowv, double h)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(rowv), "v"(h), "n"(M));
+}
+template <int K, int... J>
+__device__ __forceinline__ double hc16_row(double arow, const double (&hl)[16], std::integer_sequence<int, J...>)
+{
+    double r0 = 0.0, r1 = 0.0;
+    (fmac_row_bcast<J + K - 1>((J & 1) ? r1 : r0, arow, hl[J]), ...);         // -a[J + K] sits in lane J + K - 1 of the row
+    return r0 + r1;
+}
+__device__ __forceinline__ void iir_block_wave_hc16(const lds_f64 *x, lds_f64 *y, int n, const lds_f64 *aL, int order_, int nh0,
+                                                    const lds_f64 *hpad, double gmul)
+{
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    const int order = __builtin_amdgcn_readfirstlane(order_);
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {                                             // taps 16 q .. 16 q + 15 against x[b + 16 q + ...]
+        double H[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) H[j] = hpad[WAVE + lane - 16 * q - j];   // h[lane - 16 q - j], 0 left of the start
+        for (int b = 0; b < n; b += WAVE) {
+            double X0 = gmul * x[b + 16 * q + m];
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            asm volatile("s_nop 1" : "+v"(X0));
+            VP_BI_ROW(X0, 0)
+            const double sum = (acc0 + acc1) + (acc2 + acc3);
+            if (q == 0) y[b + lane] = sum;
+            else y[b + lane] += sum;
+        }
+    }
+    double R[16];
+    {
+        double hl[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) hl[j] = hpad[WAVE + lane - j];
+        double arow = (m + 1 <= order) ? -aL[m + 1] : 0.0;
+        asm volatile("s_nop 1" : "+v"(arow));
+#define VP_HC16_R(K) R[K - 1] = hc16_row<K>(arow, hl, std::make_integer_sequence<int, 17 - K>{});
+        VP_HC16_R(1) VP_HC16_R(2) VP_HC16_R(3) VP_HC16_R(4) VP_HC16_R(5) VP_HC16_R(6) VP_HC16_R(7) VP_HC16_R(8)
+        VP_HC16_R(9) VP_HC16_R(10) VP_HC16_R(11) VP_HC16_R(12) VP_HC16_R(13) VP_HC16_R(14) VP_HC16_R(15) VP_HC16_R(16)
+#undef VP_HC16_R
+    }
+    for (int b = 0; b < n; b += WAVE) {
+        const int kHave = (b == 0) ? min(order, nh0) : order;
+        double Y3 = 0.0;
+        if (16 - m <= kHave) Y3 = y[b - 16 + m];          // (slots beyond the order or before the frame's start: zero, never from LDS)
+        const double z = y[b + lane];
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        asm volatile("s_nop 1" : "+v"(Y3));
+        VP_BI_T(acc0, Y3, R[0], 15);  VP_BI_T(acc1, Y3, R[1], 14);  VP_BI_T(acc2, Y3, R[2], 13);  VP_BI_T(acc3, Y3, R[3], 12);
+        VP_BI_T(acc0, Y3, R[4], 11);  VP_BI_T(acc1, Y3, R[5], 10);  VP_BI_T(acc2, Y3, R[6], 9);   VP_BI_T(acc3, Y3, R[7], 8);
+        VP_BI_T(acc0, Y3, R[8], 7);   VP_BI_T(acc1, Y3, R[9], 6);   VP_BI_T(acc2, Y3, R[10], 5);  VP_BI_T(acc3, Y3, R[11], 4);
+        VP_BI_T(acc0, Y3, R[12], 3);  VP_BI_T(acc1, Y3, R[13], 2);  VP_BI_T(acc2, Y3, R[14], 1);  VP_BI_T(acc3, Y3, R[15], 0);
         y[b + lane] = z + ((acc0 + acc1) + (acc2 + acc3));
     }
 }
@@ -1925,6 +1990,10 @@ __device__ __forceinline__ void pitch_iir_wave(const VpGeom &g, const PitchLds &
             iir_block_wave_regs((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, shift > 0, hpad);
         else if (pitch_iir_hc<LITE, COMMON>(g))
             iir_block_wave_hc((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, 1.0);
+#ifndef VP_DIAG_NO_HC16_IIR
+        else if (LITE && (COMMON || order <= 16))
+            iir_block_wave_hc16((const lds_f64 *)(L.oE + shift), L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, 1.0);
+#endif
         else
             iir_block_wave(L.oE + shift, L.yF + shift, g.C, (const lds_f64 *)L.st->a, order, min(order, shift), hpad, xp, 1.0);
         return;
