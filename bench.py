@@ -211,6 +211,10 @@ def main():
                          "(auto: the pipeline above 256 streams)")
     ap.add_argument("--overlap", action="store_true",
                     help="combined mode, FAST, batched vocoder: run the pitch corrector beside the vocoder pipeline instead of behind it (vp_set_overlap)")
+    ap.add_argument("--lpc-voice", type=int, default=None,
+                    help="lpcVoice (the plugin's default is 40; BASELINE configs[2] names 24)")
+    ap.add_argument("--voc-window", default=None, choices=["512/128", "1024/256"],
+                    help="vocoder window/hop: the reference's own 512/128 (default) or the metric's 1024/256 (SURVEY section 8, cfg 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -265,8 +269,12 @@ def main():
                                       lpcVoice=48, lpcPitch=48, lpcSynth=30)
             q.prepareExplicit(FS, N, S_, 2048, 1536, 2048, 512)
         else:
-            q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"))
-            q.prepareToPlay(FS, N, S_)
+            kw = {"lpcVoice": args.lpc_voice} if args.lpc_voice else {}
+            q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **kw)
+            if args.voc_window == "1024/256":
+                q.prepareExplicit(FS, N, S_, 1024, 768, 1024, 256)       # the pitch geometry prepareToPlay(44100) picks + the metric's vocoder window
+            else:
+                q.prepareToPlay(FS, N, S_)
         q.set_yin_mode(args.yin)
         q.set_vocoder_path(args.voc_path)
         q.set_overlap(args.overlap)
@@ -470,7 +478,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"configs[4] geometry: {S} streams per GPU @48 kHz, 2048-pt frames hop 512, LPC orders 48/48/30, mode {mode}, host block N={N}" if args.cfg5 else "") or f"configs[{1 if mode == 'pitch' else 2 if mode == 'voc' else 3}]: {S} mono streams per GPU @44.1 kHz, "
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
-                                   f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else ""),
+                                   f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else "")
+                                   + (f", lpcVoice {args.lpc_voice}" if args.lpc_voice else "") + (f", vocoder window {args.voc_window}" if args.voc_window else ""),
                        "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "input": "mono voice [S][N]" if mono else "[S][3][N]", "frames_per_step": frames_per_step_gpu * n_gpus,
                        "kernel_builds": {"pitch": p.pitch_kernel_name() if mode != "voc" else None, "vocoder": p.vocoder_kernel_name() if mode != "pitch" else None},
                        "kernel_source_hash": kernel_source_hash(),

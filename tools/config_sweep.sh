@@ -14,6 +14,9 @@ exit 0
 fi
 run --mode voc --streams 256
 run --mode voc --streams 256 --iir exact
+run --mode voc --streams 256 --lpc-voice 24                          # configs[2] as BASELINE.json words it: LPC order 24
+run --mode voc --streams 256 --lpc-voice 24 --iir exact
+run --mode voc --streams 256 --lpc-voice 24 --voc-window 1024/256    # ... on the metric's 1024-pt / hop-256 window
 run --mode both --streams 256
 run --mode pitch --streams 1024
 run --mode both --streams 1024          # configs[3]: 8192 streams = 1024 per GPU

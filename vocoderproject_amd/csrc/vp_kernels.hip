@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 #ifdef VP_DIAG_NO_VOC_AC2
         const bool ac2 = false;
 #else
-        const bool ac2 = !LITE && nRoles == 1 && nPV + nPS <= 32 && (W & 1) == 0 && W > oV + 2 && W > oS + 2;
+        const bool ac2 = !LITE && nPV + nPS <= 32 && (W & 1) == 0 && W > oV + 2 && W > oS + 2;
 #endif
         if (ac2) {
             const int half = lane >> 5, l = lane & 31;
@@ -1204,7 +1204,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 #ifdef VP_DIAG_NO_LANES_LEV
         const bool lanesLev = false;
 #else
-        const bool lanesLev = !LITE && nRoles == 1 && nWaves >= 2 && W >= 128 && oV > 16 && oV <= 48;
+        const bool lanesLev = !LITE && nWaves >= 2 && W >= 128 && oV > 16 && oV <= 48;
 #endif
         if (lanesLev) {
             // the voice's recursions of the whole round on wave 0, one window per lane (spare lanes redo the last one); the
@@ -1213,7 +1213,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
                 lds_f64 *wb = gArr + 8 + (size_t)min(lane, nAct - 1) * voc_wave_doubles(W);
                 levinson_lanes<48>((const lds_f64 *)(wb + 4 * (size_t)W), wb + 4 * (size_t)W + (VP_ORDER_MAX + 1), oV, VP_ORDER_MAX + 1, g.levEps);
             } else {
-                if (activeW) levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, D);
+                if (activeW && role == 0) levinson_wave(rS, aS, oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, D);
                 if (waveHw == 1) {
                     lds_f64 *wb = gArr + 8, *rS0 = wb + 4 * (size_t)W + 2 * (VP_ORDER_MAX + 1);
                     levinson_wave(rS0, rS0 + (VP_ORDER_MAX_SYNTH + 1), oS, VP_ORDER_MAX_SYNTH + 1, g.levEps, wb + 3 * (size_t)W);
@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void vocoder_block(const VpGeom &g, const VpCall &c, 
 #ifdef VP_DIAG_NO_LANES_ENERGY
         const bool lanesE = false;
 #else
-        const bool lanesE = !LITE && nRoles == 1 && nWaves >= 2 && (W & 1) == 0;
+        const bool lanesE = !LITE && nWaves >= 2 && (W & 1) == 0;
 #endif
         if (lanesE) {                                    // wave 0: the round's eVoice sums, wave 1: its eSynth sums, a window per lane
             if (waveHw < 2) {
