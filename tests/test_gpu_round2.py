@@ -617,3 +617,32 @@ def test_fast_block_recursion_for_orders_17_to_48(order):
         assert np.sqrt((err ** 2).mean()) < 1e-4
         assert np.abs(err).max() <= 4e-7 * scale, (order, N, np.abs(err).max(), scale)
         assert np.abs(ref).max() > 0.01, "vacuous comparison"
+
+
+@pytest.mark.parametrize("order", [2, 7, 15, 16])
+def test_fast_block_recursion_of_the_register_light_builds(order):
+    """Above 256 streams the FAST recursion of pitch orders up to 16 runs as four 16-tap zero-state passes plus a 16-entry
+    history row (iir_block_wave_hc16; the 128-VGPR builds cannot hold the 64 taps of the regular form).  Same tolerance as every
+    FAST path, against the oracle on a sample of streams; batch position must not matter."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    import test_gpu_parity as T
+    S, N, B = 260, 1024, 12
+    base = T._streams(13, N * B)
+    base[1, 0] *= np.where((np.arange(N * B) // 5000) % 2 == 0, 1.0, 1e-6).astype(np.float32)     # gate closes and reopens
+    x = np.ascontiguousarray(np.tile(base, (20, 1, 1)))
+    params = dict(lpcPitch=order, vocBool=0)
+    p = BatchVocoderProcessor(**params)
+    p.prepareToPlay(T.FS, N, S)
+    p.set_iir_mode("fast")
+    p.set_yin_mode("xcorr")
+    assert p.pitch_kernel_name().startswith("vp_k_pitch_lite_fast")
+    got = p.run(x)
+    pick = [0, 1, 5, 12]
+    ref = T._oracle_run(base[pick], N, params)
+    err = got[pick].astype(np.float64) - ref
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.isfinite(got).all()
+    assert np.sqrt((err ** 2).mean()) < 1e-4
+    assert np.abs(err).max() <= 4e-7 * scale, (order, np.abs(err).max(), scale)
+    assert np.abs(ref).max() > 0.01, "vacuous comparison"
+    np.testing.assert_array_equal(got[1], got[1 + 13 * 19])
