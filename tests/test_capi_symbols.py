@@ -61,7 +61,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "vocoderproject_amd")
     for dp, _, fs in os.walk(pkg):
         for f in fs:
-            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+            if f.endswith((".py", ".hip", ".inc", ".h", ".hpp", ".cpp")):
                 t = open(os.path.join(dp, f), errors="ignore").read()
                 assert "import oracle" not in t and "from oracle" not in t and "vp_oracle" not in t, f
 

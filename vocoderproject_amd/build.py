@@ -19,7 +19,8 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libvp_amd.so")
 SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_capi.hip"]
-DEPS = SOURCES + ["vp_common.h", "vp_kernels.h", "vp_voc2.h"]
+PARTS = ["vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc"]      # included by vp_kernels.hip
+DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h"]
 ARCH = "gfx950"
 NUM_TUS = 5          # groups of kernels in vp_kernels.hip (VP_TU)
 
@@ -75,8 +76,8 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             src, obj, extra = job
             cmd = common + extra + ["-c", src, "-o", obj]
             hsh = hashlib.sha256(" ".join(cmd[:-1]).replace(tmp, "").encode())
-            deps = {"vp_kernels.hip": ["vp_kernels.hip", "vp_common.h"],
-                    "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"]}.get(os.path.basename(src))
+            deps = {"vp_kernels.hip": ["vp_kernels.hip", "vp_common.h"] + PARTS,
+                    "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"] + PARTS}.get(os.path.basename(src))
             if deps is None:
                 deps = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.basename(src), os.path.join(ROOT, "include", "vp_amd.h")]
             for dep in deps:
