@@ -103,3 +103,29 @@ int main() {
     import torch
     rc = subprocess.call([str(exe)])
     assert rc == (0 if torch.cuda.is_available() else 42)
+
+
+def test_source_hash_and_build_dependencies_cover_every_included_kernel_source():
+    """bench.py ties profiles/*_counters.json to the kernel sources by a hash, and the build caches objects by one: both must
+    see every file the kernel translation units include (a part added to vp_kernels.hip and forgotten there would let a stale
+    counter file or a stale object pass for current)."""
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from vocoderproject_amd import build
+    csrc = os.path.join(ROOT, "vocoderproject_amd", "csrc")
+    seen, todo = set(), ["vp_kernels.hip", "vp_voc2.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^#include "([^"]+)"', open(os.path.join(csrc, f)).read(), re.M):
+            if os.path.exists(os.path.join(csrc, inc)):
+                todo.append(inc)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    hashed = set(re.findall(r'"vocoderproject_amd/csrc/([^"]+)"', src[src.index("def kernel_source_hash"):src.index("def committed_counters")]))
+    assert seen <= hashed, seen - hashed
+    assert seen <= set(build.DEPS), seen - set(build.DEPS)
+    assert len(bench.kernel_source_hash()) == 16
