@@ -64,7 +64,8 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     # The PRODUCT library keeps vp_kernels.hip in one translation unit: measured on the same box, the same kernels run
     # 1.3 % slower out of per-group code objects (instruction placement; tools/ab.sh).  The diagnostic twins take the
     # fast build.
-    groups = [0] if not (stamps or poison) else list(range(1, NUM_TUS + 1))
+    # (VP_SPLIT_BUILD=1: the development loop -- the product library from per-group objects too, 40 s instead of 3 min)
+    groups = [0] if not (stamps or poison or os.environ.get("VP_SPLIT_BUILD") == "1") else list(range(1, NUM_TUS + 1))
     with tempfile.TemporaryDirectory(prefix="vp_build_") as tmp:
         jobs = [(os.path.join(CSRC, "vp_kernels.hip"), os.path.join(tmp, f"k{k}.o"), [f"-DVP_TU={k}"]) for k in groups]
         jobs.append((os.path.join(CSRC, "vp_voc2.hip"), os.path.join(tmp, "voc2.o"), []))     # the batched vocoder pipeline (includes vp_kernels.hip's helpers)

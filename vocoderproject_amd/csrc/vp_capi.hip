@@ -118,7 +118,8 @@ static bool pitch_lite(const vp_handle *h, bool iirFast, bool yinFft)
 // geometry and order for which the common-case builds (vp_k_pitch*_c) are valid
 static bool pitch_common(const vp_handle *h)
 {
-    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512;
+    // (the last term: room behind the YIN window's prefix sums in eFrame for the quarter sums of xcorr8_quarter, vp_pitch.inc xc8_ok)
+    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512 && h->g.eLen >= h->g.F + 4 * h->g.tauMax + 1;
 }
 
 // THE selection of the pitch-kernel build for a launch (used by the launch site and by vp_pitch_kernel_name alike)

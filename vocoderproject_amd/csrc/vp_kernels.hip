@@ -77,6 +77,9 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_LEV_ROW48
 #define VP_LEV_ROW48 1          /* orders 16..48 of the pitch LPC: the three-register row form (levinson_row48); 0 = the forms it replaced */
 #endif
+#ifndef VP_LPC_FAST
+#define VP_LPC_FAST 1           /* VP_IIR_FAST: LPC autocorrelation with the sum over n split across the lanes (autocorr_rows_fast); 0 = the ordered sums */
+#endif
 #ifndef VP_XC_ACSPLIT
 #define VP_XC_ACSPLIT 11        /* sixteenths of the LPC autocorrelation summed beside the cross-correlation YIN */
 #endif
