@@ -16,6 +16,7 @@ PHASES = {0: "pitch: load xs", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/n
           4: "pitch: st marks", 5: "pitch: levinson", 6: "pitch: FIR start", 7: "pitch: psola", 8: "pitch: IIR",
           9: "pitch: fill output", 12: "pitch:   (cum sum)", 13: "pitch:   (normalise)", 14: "pitch:   (psola qtab+grain table)", 10: "pitch: FIR cont", 11: "pitch: state out",
           24: "pitch:   (block IIR carry-in, all chunks)", 25: "pitch:   (block IIR 64-term dot, all chunks)",
+          28: "pitch:   (an marks: roll + first mark)", 29: "pitch:   (an marks: walk to the right)",
           26: "pitch:   (last wave: LPC autocorrelation)", 27: "pitch:   (last wave: Levinson-Durbin)",
           40: "pitch:   (YIN phase, wave 0 busy)", 41: "pitch:   (YIN phase, wave 1 busy)", 42: "pitch:   (YIN phase, wave 2 busy)",
           43: "pitch:   (YIN phase, wave 3 busy)", 44: "pitch:   (YIN phase, wave 4 busy)", 45: "pitch:   (YIN phase, wave 5 busy)",
