@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("VP_AMD_LIB", os.path.join(ROOT, "vocoderproject_amd", "libvp_amd_stamps.so"))
 
-PHASES = {0: "pitch: load xs", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/normalise/pick", 3: "pitch: an marks",
+PHASES = {15: "pitch: prologue (ingest, gate, state/frame/window loads)", 0: "pitch: loop top", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/normalise/pick", 3: "pitch: an marks",
           4: "pitch: st marks", 5: "pitch: levinson", 6: "pitch: FIR start", 7: "pitch: psola", 8: "pitch: IIR",
           9: "pitch: fill output", 12: "pitch:   (cum sum)", 13: "pitch:   (normalise)", 14: "pitch:   (psola qtab+grain table)", 10: "pitch: FIR cont", 11: "pitch: state out",
           24: "pitch:   (block IIR carry-in, all chunks)", 25: "pitch:   (block IIR 64-term dot, all chunks)",
@@ -21,6 +21,8 @@ PHASES = {0: "pitch: load xs", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/n
           40: "pitch:   (YIN phase, wave 0 busy)", 41: "pitch:   (YIN phase, wave 1 busy)", 42: "pitch:   (YIN phase, wave 2 busy)",
           43: "pitch:   (YIN phase, wave 3 busy)", 44: "pitch:   (YIN phase, wave 4 busy)", 45: "pitch:   (YIN phase, wave 5 busy)",
           46: "pitch:   (YIN phase, wave 6 busy)", 47: "pitch:   (YIN phase, wave 7 busy)",
+          48: "pitch:   (scan phase, wave 0 busy)", 49: "pitch:   (scan phase, wave 1 busy)", 50: "pitch:   (scan phase, wave 2 busy)",
+          54: "pitch:   (scan phase, wave 6 busy)", 55: "pitch:   (scan phase, wave 7 busy)",
           16: "voc: load", 17: "voc: autocorr", 18: "voc: levinson", 19: "voc: FIR", 20: "voc: energies",
           21: "voc: gains", 22: "voc: IIR", 23: "voc: scale+OLA"}
 

@@ -60,7 +60,7 @@ struct vp_handle {
     float *stageInB = nullptr, *stageOutB = nullptr; int stageBlocks = 0;   // vp_process_blocks: grow-only, [B][S][3|2][N]
     hipStream_t ownStream = nullptr;
     int vocWaves = 8;
-    size_t vocLds = 0, pitchLds = 0;
+    size_t vocLds = 0, pitchLds = 0, ldsMax = 0;
     int prof = 0;                               // 0 off, k: every k-th launch is bracketed with events
     unsigned profTick = 0;
     bool profThis = false;                      // the call in hand is a sampled one
@@ -525,6 +525,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
         }
     }
     h->pitchLds = vp_pitch_lds_bytes(g);
+    h->ldsMax = ldsMax;
     // FFT accelerator: smallest power of two >= F + tauMax, if its work arrays still fit
     g.fftLog = 0;
     {
@@ -864,7 +865,12 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
                 cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
                 ProfScope ps(h, st, 2);
-                const PitchPlan plan = pitch_plan(h, cp.iirFast != 0, cp.yinFft != 0, nBlocks);
+                PitchPlan plan = pitch_plan(h, cp.iirFast != 0, cp.yinFft != 0, nBlocks);
+                // one workgroup per CU anyway (S <= 256 or a frame beyond half a CU's LDS): the block's accumulator slice rides in LDS
+                if (nBlocks == 1 && !cp.yinFft && !pitch_lite(h, cp.iirFast != 0, false) && plan.lds + vp_pitch_acc_lds_bytes(g) + 16 <= h->ldsMax) {
+                    cp.ldsAcc = 1;
+                    plan.lds = ((plan.lds + 15) / 16) * 16 + vp_pitch_acc_lds_bytes(g);
+                }
                 cp.ldsBytes = (int)plan.lds;
                 hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
             }

@@ -54,6 +54,9 @@ struct VpCall {
                                  // already (nothing to write, nothing to sum for its gate)
     int nBlocks;                 // pitch kernel with both fusions: consecutive blocks handled by this launch (>= 1);
                                  // the counters above describe the first, the kernel advances them itself
+    int ldsAcc;                  // pitch kernel: the launch carries vp_pitch_acc_lds_bytes() more dynamic LDS, in which the block's
+                                 // slice of the output accumulator lives while the chunks add to it (one read and one write
+                                 // of HBM per block instead of a read-modify-write per chunk)
 };
 
 // The per-block parameters of ONE stream (each stream is a plugin instance with its own treeState).  They live in
@@ -113,6 +116,15 @@ struct VpDev {
 // tauMax + 1 is smaller than that scratch, the regions are sized for the scratch instead.
 VP_HD static inline int vp_dy_len(int tauMax) { const int need = 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2; return tauMax + 1 > need ? tauMax + 1 : need; }
 VP_HD static inline int vp_cum_len(int tauMax) { return tauMax + 1 > 448 ? tauMax + 1 : 448; }
+
+// bytes of dynamic LDS vp_k_pitch needs for a geometry
+VP_HD static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
+{
+    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (2 * (size_t)g.tauMax + 2);
+    return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
+}
+// extra dynamic LDS for the block's slice of the output accumulator (VpCall::ldsAcc), placed behind vp_pitch_lds_bytes()
+VP_HD static inline size_t vp_pitch_acc_lds_bytes(const VpGeom &g) { return ((size_t)g.N + g.C) * sizeof(double) + 16; }
 
 // doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
 VP_HD static inline size_t voc_wave_doubles(int W)

@@ -21,12 +21,7 @@ __global__ void vp_k_pitch_fft(VpGeom g, VpCall c, VpDev d, const float *__restr
 __global__ void vp_k_pitch_fast_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
 
-// bytes of dynamic LDS vp_k_pitch needs for a geometry
-static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
-{
-    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (2 * (size_t)g.tauMax + 2);
-    return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
-}
+
 // extra dynamic LDS of the VP_YIN_FFT accelerator (re/im arrays)
 static inline size_t vp_pitch_fft_lds_bytes(const VpGeom &g) { return g.fftLog ? ((size_t)3 << g.fftLog) * sizeof(double) : 0; }   // re, im, twiddles
 static inline size_t vp_voc_lds_bytes(int W, int nWaves)

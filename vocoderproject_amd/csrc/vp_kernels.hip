@@ -116,7 +116,7 @@ __device__ __forceinline__ int vp_stream(const VpDev &d)
 
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
-                                           const lds_state *stl = nullptr, int boff = 0);
+                                           const lds_state *stl = nullptr, int boff = 0, const lds_f64 *oA = nullptr);
 
 __device__ __forceinline__ int ring_pos(int curr, int idx, int inSize)
 {
@@ -237,8 +237,9 @@ __global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDe
 // K3: emit.  addDryVoice / addSynth (MyBuffer.cpp:309-448) + fillOutputBuffer + clearOutput
 // (MyBuffer.cpp:113-133, 218-228).  out[ch] = float(((acc + dry) + synth_ch)); the consumed region of
 // the accumulator is zeroed.
+// oA: the pitch kernel's LDS copy of the block's accumulator slice (logical positions from outCounter), read instead of HBM
 __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, const VpDev &d, float *__restrict__ out,
-                                           const lds_state *stl, int boff)
+                                           const lds_state *stl, int boff, const lds_f64 *oA)
 {
     const int s = vp_stream(d);
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
@@ -254,7 +255,7 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
     for (int i = threadIdx.x; i < g.N; i += blockDim.x) {
         int pos = (c.outCounter + boff + i) % g.outSize;
         int pin = (c.currCounter + boff + i) % g.inSize;
-        double v = acc[pos];
+        double v = oA ? oA[i] : acc[pos];
         if (acc2) { v += acc2[pos]; acc2[pos] = 0.0; }                       // the pitch corrector's share, when it ran beside the vocoder
         if (dryOn) v += (double)vr[pin] * gainVoice;
         double l = v, r = v;
