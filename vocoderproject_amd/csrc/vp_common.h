@@ -123,8 +123,9 @@ VP_HD static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
     size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (2 * (size_t)g.tauMax + 2);
     return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
 }
-// extra dynamic LDS for the block's slice of the output accumulator (VpCall::ldsAcc), placed behind vp_pitch_lds_bytes()
-VP_HD static inline size_t vp_pitch_acc_lds_bytes(const VpGeom &g) { return ((size_t)g.N + g.C) * sizeof(double) + 16; }
+// extra dynamic LDS for the block's slice of the output accumulator (VpCall::ldsAcc) and, behind it, a deferred chunk's input
+// and history (PitchLds::pend), placed behind vp_pitch_lds_bytes()
+VP_HD static inline size_t vp_pitch_acc_lds_bytes(const VpGeom &g) { return ((size_t)g.N + g.C + 1 + g.C + 128) * sizeof(double) + 16; }
 
 // doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
 VP_HD static inline size_t voc_wave_doubles(int W)

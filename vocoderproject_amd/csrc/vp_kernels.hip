@@ -80,6 +80,9 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_LPC_FAST
 #define VP_LPC_FAST 1           /* VP_IIR_FAST: LPC autocorrelation with the sum over n split across the lanes (autocorr_rows_fast); 0 = the ordered sums */
 #endif
+#ifndef VP_AC_ROWS
+#define VP_AC_ROWS 1            /* exact modes, orders below 32: LPC autocorrelation with lane-parallel products and DPP-ordered sums (autocorr_rows_exact8) */
+#endif
 #ifndef VP_XC_ACSPLIT
 #define VP_XC_ACSPLIT 11        /* sixteenths of the LPC autocorrelation summed beside the cross-correlation YIN */
 #endif
