@@ -26,7 +26,15 @@ Besides the contract fields the line carries
                   all-reduced sum of ranks
   exchange     -- SURVEY 8(e)'s root fan-out/fan-in: rank 0 holds the whole batch, per step scatter_streams ->
                   processBlock -> gather_streams, double-buffered; frames/s beside the resident-input `value`
+  configs2     -- BASELINE configs[2]: 256 streams, vocoder, lpcVoice 24, on the reference's 512/128 window and on the
+                  metric's 1024/256 window
   configs3     -- the same hot path at BASELINE configs[3]'s per-GPU share (1024 streams, pitch + vocoder)
+  configs4     -- BASELINE configs[4]'s per-GPU share: 48 kHz, 2048-pt frames hop 512, orders 48/48/30, 512 streams, both
+                  processes (its frames are 512-sample hops)
+  value_long   -- the headline workload again over >= 2000 steps (a 20-step driver run times 1.7 ms; this is the stable figure)
+The per-kernel durations (`kernel_us`, `roofline.avg_kernel_us`) are HIP events around every 8th launch of THE timed region;
+`value_long` runs without any event record, and `roofline.step_us_without_events` is its time per step (one launch per step: an
+upper bound of the kernel's duration that carries no event overhead).
 """
 import argparse
 import hashlib
@@ -49,7 +57,7 @@ PROFILE_EVERY = 8       # kernel durations are sampled live inside the timed reg
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md
 UNIQUE_BLOCKS = 16                                                      # synthetic input ring, cycled
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
 
 
 def usable_cores():
@@ -77,7 +85,7 @@ def kernel_source_hash():
 
 
 def committed_counters(kernel, workload_key):
-    """Per-launch PMC figures of `kernel` at `workload_key` from profiles/r02_counters.json (tools/collect_counters.sh:
+    """Per-launch PMC figures of `kernel` at `workload_key` from profiles/r03_counters.json (tools/collect_counters.sh:
     separate rocprofv3 --pmc passes of this very command); None unless kernel build name AND source hash match."""
     try:
         with open(COUNTERS_JSON) as f:
@@ -147,19 +155,41 @@ def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
             "hbm_gbs": (2 * S * T * 4 + 2 * frames * F * 4) / dt / 1e9}
 
 
+def count_gpus_without_hip():
+    """GPUs this process may use, counted WITHOUT touching HIP (the parent of the rank processes must not initialise the
+    runtime): the KFD topology lists every agent, GPU nodes are the ones with SIMDs; HIP_/ROCR_VISIBLE_DEVICES narrow it."""
+    n = 0
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in sorted(os.listdir(top)):
+            with open(os.path.join(top, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None                                  # no KFD here: let the ranks find out
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n, argv):
-    """`python bench.py --gpus N` without a launcher: N rank processes, one per GPU, started from a parent that has not
-    initialised the GPU (torch.cuda.device_count() does not).  Rank 0's stdout is this process's stdout."""
-    import torch
-    have = torch.cuda.device_count()
-    if have < n:
+    """`python bench.py --gpus N` without a launcher: N rank processes, one per GPU, started from a parent that never
+    touches HIP (the GPUs are counted from the KFD topology in sysfs).  Rank 0's stdout is this process's stdout."""
+    have = count_gpus_without_hip()
+    if have is not None and have < n:
         print(f"bench.py --gpus {n}: this node exposes {have} GPU(s)", file=sys.stderr)
         return 2
-    with socket.socket() as s:
+    with socket.socket() as s:                       # (a free port at this instant; the ranks rendezvous on it a moment later)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; without it RCCL's intra-node
+        # transport (hipIpcGetMemHandle) fails with "invalid argument".  The image exports it already; kept explicit for
+        # environments built from scratch.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
@@ -395,57 +425,90 @@ def main():
 
     # the batch lives on rank 0; per step root fan-out (scatter_streams), processBlock on every rank, root
     # fan-in (gather_streams).  Double-buffered: step i+1's scatter and step i-1's gather ride RCCL's stream beside step
-    # i's kernels.  Same handle, same streams as the resident-input region above.
-    exch = None
-    if do_exchange:
-        C_in = 1 if mono else 3
-        tail_in = (N,) if mono else (3, N)
-        Sg = S * world
+    # i's kernels (exchange_steps enqueues on torch's CURRENT stream: the processor is handed that same stream).
+    def exchange_region(q, S_, N_, fs_, hop_, mono_, ke):
+        C_in = 1 if mono_ else 3
+        tail_in = (N_,) if mono_ else (3, N_)
+        Sg = S_ * world
+        xr = yr = None
         if rank == 0:
-            xr = make_streams(Sg, N * U, fs=FS, first_stream=0, device=dev).view(Sg, 3, U, N).permute(2, 0, 1, 3)
-            xr = (xr[:, :, 0, :] if mono else xr).contiguous()                     # [U][Sg][N] or [U][Sg][3][N]
-            yr = [torch.empty((Sg, 2, N), dtype=torch.float32, device=dev) for _ in range(2)]
-        p.set_iir_mode(args.iir)
+            xr = make_streams(Sg, N_ * 4, fs=fs_, first_stream=0, device=dev).view(Sg, 3, 4, N_).permute(2, 0, 1, 3)
+            xr = (xr[:, :, 0, :] if mono_ else xr).contiguous()                  # [4][Sg][N] or [4][Sg][3][N]
+            yr = [torch.empty((Sg, 2, N_), dtype=torch.float32, device=dev) for _ in range(2)]
 
-        def run_exchange(steps):
+        def run(steps):
             def proc(i_, o_):
-                if mono:
-                    p.process_mono_device(i_, o_, stream.cuda_stream)
+                if mono_:
+                    q.process_mono_device(i_, o_, stream.cuda_stream)
                 else:
-                    p.process_device(i_, o_, stream.cuda_stream)
-            exchange_steps(steps, Sg, (lambda i: xr[i % U]), (lambda i: yr[i & 1]), tail_in, (2, N), torch.float32, dev, proc)
+                    q.process_device(i_, o_, stream.cuda_stream)
+            exchange_steps(steps, Sg, (lambda i: xr[i % 4]), (lambda i: yr[i & 1]), tail_in, (2, N_), torch.float32, dev, proc)
 
-        ke = max(16, args.steps // 2)
-        run_exchange(4)
+        run(4)
         torch.cuda.synchronize(dev)
         dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        run_exchange(ke)
+        run(ke)
         torch.cuda.synchronize(dev)
         dist.barrier()
         torch.cuda.synchronize(dev)
         (dte,) = max_over_ranks(time.perf_counter() - t0)
-        exch = {"value": frames_per_step_gpu * ke * n_gpus / dte, "unit": "frames/s", "ms_per_step": dte / ke * 1e3, "steps": ke,
-                "bytes_scattered_per_step": (Sg - S) * C_in * N * 4, "bytes_gathered_per_step": (Sg - S) * 2 * N * 4,
+        return {"value": (S_ * N_ // hop_) * ke * n_gpus / dte, "unit": "frames/s", "ms_per_step": dte / ke * 1e3, "steps": ke,
+                "bytes_scattered_per_step": (Sg - S_) * C_in * N_ * 4, "bytes_gathered_per_step": (Sg - S_) * 2 * N_ * 4,
                 "what": "rank 0 holds the batch: scatter_streams -> processBlock -> gather_streams per step, double-buffered, "
                         "RCCL point-to-point (batch_isend_irecv); root's own shard is a local copy"}
 
-    # BASELINE configs[3]'s per-GPU share (8192 streams over 8 GPUs = 1024 per GPU, pitch corrector + vocoder), same geometry
-    cfg3 = None
-    if not args.single_mode and not args.cfg5 and BPS == 1 and not (mode == "both" and S == 1024):
-        S3 = 1024
-        p3 = make_processor("both", S3)
-        p3.set_iir_mode(args.iir)
-        x3 = make_streams(S3, N * 4, fs=FS, first_stream=rank * S3, device=dev).view(S3, 3, 4, N).permute(2, 0, 1, 3).contiguous()
-        y3 = torch.empty((S3, 2, N), dtype=torch.float32, device=dev)
-        k4 = max(8, args.steps // 8)
-        dt3 = region(lambda i: p3.process_device(x3[i % 4], y3, stream.cuda_stream), k4, 3)
-        (dt3,) = max_over_ranks(dt3)
-        cfg3 = {"value": (S3 * N // HOP) * k4 * n_gpus / dt3, "unit": "frames/s", "ms_per_step": dt3 / k4 * 1e3, "steps": k4,
-                "streams_per_gpu": S3, "mode": "both", "iir_mode": args.iir,
-                "kernel_builds": {"pitch": p3.pitch_kernel_name(), "vocoder": p3.vocoder_kernel_name()}}
-        del p3, x3, y3
+    exch = None
+    if do_exchange:
+        p.set_iir_mode(args.iir)
+        exch = exchange_region(p, S, N, FS, HOP, mono, max(16, args.steps // 2))
+
+    # the headline workload once more, long and without any event record: the stable figure beside a 20-step driver run
+    value_long = None
+    if not args.single_mode and BPS == 1:
+        p.set_iir_mode(args.iir)
+        kl = max(2000, args.steps)
+        dtl = region(step, kl, 8)
+        (dtl,) = max_over_ranks(dtl)
+        value_long = {"value": frames_per_step_gpu * kl * n_gpus / dtl, "steps": kl, "ms_per_step": dtl / kl * 1e3}
+
+    # The other BASELINE configs at their per-GPU share, so that one driver run (at every N) carries a figure for each of them.
+    def leg(what, mode_, S_, fs_, N_, hop_, prepare, params, steps_, with_exchange=False):
+        q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **params)
+        if prepare:
+            q.prepareExplicit(fs_, N_, S_, *prepare)
+        else:
+            q.prepareToPlay(fs_, N_, S_)
+        q.set_yin_mode(args.yin)
+        q.set_iir_mode(args.iir)
+        xl = make_streams(S_, N_ * 4, fs=fs_, first_stream=rank * S_, device=dev).view(S_, 3, 4, N_).permute(2, 0, 1, 3).contiguous()
+        yl = torch.empty((S_, 2, N_), dtype=torch.float32, device=dev)
+        dtl_ = region(lambda i: q.process_device(xl[i % 4], yl, stream.cuda_stream), steps_, 3)
+        (dtl_,) = max_over_ranks(dtl_)
+        out_ = {"workload": what, "value": (S_ * N_ // hop_) * steps_ * n_gpus / dtl_, "unit": "frames/s", "frame_hop": hop_,
+                "ms_per_step": dtl_ / steps_ * 1e3, "steps": steps_, "streams_per_gpu": S_, "mode": mode_, "iir_mode": args.iir,
+                "alg_bytes_per_step_per_gpu": ALG_BYTES_PER_FRAME[mode_] * (S_ * N_ // 256),
+                "kernel_builds": {"pitch": q.pitch_kernel_name() if mode_ != "voc" else None,
+                                  "vocoder": q.vocoder_kernel_name() if mode_ != "pitch" else None}}
+        out_["hbm_frac_algorithmic"] = out_["alg_bytes_per_step_per_gpu"] / (dtl_ / steps_) / 1e9 / HBM_PEAK_GBS
+        if do_exchange and with_exchange:
+            out_["exchange"] = exchange_region(q, S_, N_, fs_, hop_, False, max(8, steps_ // 2))
+        del q, xl, yl
+        return out_
+
+    cfg2 = cfg3 = cfg4 = None
+    k4 = max(8, args.steps // 8)
+    if not args.single_mode and not args.cfg5 and BPS == 1:
+        if not (mode == "voc" and args.lpc_voice == 24):
+            cfg2 = {"window_512_128": leg("configs[2]: 256 streams, vocoder, lpcVoice 24, the reference's 512/128 window", "voc", 256, 44100.0, 1024, 256,
+                                          None, {"lpcVoice": 24}, k4),
+                    "window_1024_256": leg("configs[2]: 256 streams, vocoder, lpcVoice 24, the metric's 1024/256 window", "voc", 256, 44100.0, 1024, 256,
+                                           (1024, 768, 1024, 256), {"lpcVoice": 24}, k4)}
+        if not (mode == "both" and S == 1024):
+            cfg3 = leg("configs[3] per GPU: 1024 streams, pitch corrector + vocoder", "both", 1024, 44100.0, 1024, 256, None, {}, k4, with_exchange=True)
+        cfg4 = leg("configs[4] per GPU: 512 streams @48 kHz, 2048-pt frames hop 512, orders 48/48/30, pitch corrector + vocoder", "both", 512,
+                   48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(6, args.steps // 16))
 
     total_frames = frames_per_step_gpu * args.steps * n_gpus
     value = total_frames / dt
@@ -496,8 +559,15 @@ def main():
             out["rccl"] = rccl
         if exch:
             out["exchange"] = exch
+        if value_long:
+            out["value_long"] = value_long
+            roof["step_us_without_events"] = value_long["ms_per_step"] * 1e3
+        if cfg2:
+            out["configs2"] = cfg2
         if cfg3:
             out["configs3"] = cfg3
+        if cfg4:
+            out["configs4"] = cfg4
         if not args.single_mode:
             out["stft_kernel"] = stft_figure(dev, S)
         if n_gpus == 1 and not args.no_cpu:
