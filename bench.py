@@ -167,7 +167,7 @@ def count_gpus_without_hip():
             if int(props.get("simd_count", "0")) > 0:
                 n += 1
     except (OSError, ValueError):
-        return None                                  # no KFD here: let the ranks find out
+        return 0                                     # no KFD: no AMD GPU this process could open
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -179,7 +179,7 @@ def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: N rank processes, one per GPU, started from a parent that never
     touches HIP (the GPUs are counted from the KFD topology in sysfs).  Rank 0's stdout is this process's stdout."""
     have = count_gpus_without_hip()
-    if have is not None and have < n:
+    if have < n:
         print(f"bench.py --gpus {n}: this node exposes {have} GPU(s)", file=sys.stderr)
         return 2
     with socket.socket() as s:                       # (a free port at this instant; the ranks rendezvous on it a moment later)

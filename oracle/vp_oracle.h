@@ -31,11 +31,21 @@
  *     - pinned (SURVEY.md Appendix A / section 3.1 known answers recorded from a survey-session run of the
  *       compiled reference): Notes::getClosestFreq KATs, prepareToPlay geometry (latency,
  *       inSize, outSize, tauMax at 44.1 kHz and 48 kHz), "ch2 returns 0".
- *     - PARITY UNPINNED: end-to-end processBlock() output as a whole (every stage of it is pinned above except the
- *       ones listed here), the mark branches methods.py does not share with the plugin (voiced->voiced without marks
- *       in the overlap; getClosestAnMarkIdx's incomplete-grain fallbacks :804-812 and the Q2/Q3 reads), the chunk
- *       scheduling of PSOLA (Q5: the notebook works per frame), MyBuffer's ring/counter arithmetic, and the JUCE
- *       arithmetic surface (getRMSLevel, Decibels, ScopedNoDenormals), restated from JUCE 5.4.x documented semantics.
+ *     - pinned in round 3, END TO END (tests/golden/gen_pitch_corrector_vectors.py executes the notebook's own multi-frame
+ *       `pitch_corrector` loop -- ipynb cell 9, loaded from /root/reference at run time, run with the plugin's geometry ->
+ *       pitch_corrector_vectors.npz): pitch-only processBlock() over 29 frames of six steadily voiced streams (beta below and
+ *       above 1, chromatic and two major keys): YIN, analysis and synthesis marks agree frame by frame, and the float32 output is
+ *       the notebook's BIT FOR BIT on the frames' exclusive parts (146 of 148 stretches) and on the half-Hann cross-fades wherever
+ *       the old frame's last grain stays inside its frame -- which pins the chain of stages, the half-Hann overlap-add
+ *       (PitchProcess.cpp:328-342), the chunk schedule (:166-196) and MyBuffer's latency alignment (plugin sample t = notebook
+ *       sample t - 1024 + 697).  Where the two legitimately differ is counted and reported by the test: SURVEY Q5 (late grains
+ *       dropped by the chunked synthesis), the residual samples that only the plugin has when it synthesises a frame's last
+ *       chunk, int() vs round() of the new period, pitch > 10 vs > 1.
+ *     - PARITY UNPINNED (what is left): the vocoder's 10-deep energy-history gain over several windows and its overlap-add
+ *       (VocoderProcess.cpp:264-275, 291-327; one window at a time is pinned above), the mark branches methods.py does not
+ *       share with the plugin (voiced->voiced without marks in the overlap; getClosestAnMarkIdx's incomplete-grain fallbacks
+ *       :804-812 and the Q2/Q3 reads), the whole-ring RMS gate, and the JUCE arithmetic surface (getRMSLevel, Decibels,
+ *       ScopedNoDenormals), restated from JUCE 5.4.x documented semantics.
  *
  * Every function cites the reference file:line it restates (paths relative to
  * /root/reference/Source/).

@@ -1,0 +1,114 @@
+"""Generate tests/golden/pitch_corrector_vectors.npz by EXECUTING the reference notebook's own `pitch_corrector` loop
+(Notebook/"Pitch Corrector and Vocoder.ipynb", cell 9: YIN -> analysis marks -> synthesis marks -> LPC -> residual -> PSOLA ->
+all-pole filter -> st_window overlap-add, over many frames) and its synthesis-window cell (cell 7), loaded from
+/root/reference at run time -- nothing of the notebook is copied or stored, only inputs and outputs (data).
+
+    python tests/golden/gen_pitch_corrector_vectors.py
+
+What it pins (round-2 verdict, item 6): the plugin's pitch-only processBlock() END TO END on steadily voiced streams -- the
+chain of stages, the half-Hann overlap-add of consecutive frames and the frame grid/latency alignment of MyBuffer --, against
+the one multi-frame flow the reference ships in runnable form.  The notebook is "a different parametrisation" (its cell 0 says
+so); it is run here with the PLUGIN's geometry (frames of 1024 every 768 samples, tau_max = ceil(fs / 100) = 441, LPC order 15,
+f_min 100, f_max 800) so that the two are comparable.  Known, legitimate differences (tests/test_oracle_golden.py reports the
+residual and where it comes from):
+  * the plugin synthesises a frame in four chunks and drops PSOLA contributions that land in a chunk already filtered
+    (PitchProcess.cpp:685); the notebook does a frame at once;
+  * the notebook's residual starts from a zero filter state at i - tau_max, the plugin's at startSample - samplesToKeep;
+  * the notebook rounds the new period with int(), the plugin with round() (cases where both agree are generated);
+  * voiced means pitch > 10 in the notebook, pitch > 1 in the plugin (no difference for real pitches).
+
+Alignment: the plugin's frame m starts at input sample m * 768 - 1024 (latency 1024, MyBuffer.h:37-43), the notebook's frame k at
+tau_max + k * 768 of ITS input.  The notebook is therefore fed the plugin's input delayed by D = tau_max + 1024 - 768 = 697
+samples (zeros in front): its frame k is the plugin's frame k + 1 sample for sample, and plugin output sample t corresponds to
+notebook output sample t - 1024 + 697 (stored here as `shift`).
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference/Notebook")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NB = "/root/reference/Notebook/Pitch Corrector and Vocoder.ipynb"
+FS = 44100
+
+
+def notebook_namespace(key):
+    """The notebook's cells 1 (imports), 7 (synthesis window) and 9 (pitch_corrector), executed with the plugin's parameters in place of
+    cell 5's."""
+    nb = json.load(open(NB))
+    cells = ["".join(c["source"]) for c in nb["cells"]]
+    assert "def pitch_corrector" in cells[9] and "st_window" in cells[7]
+    ns = {}
+    exec("import scipy.signal as sp\nimport numpy as np\nfrom methods import *\n", ns)       # cell 1 without wavio / IPython
+    # cell 5 with the plugin's values (PluginProcessor.cpp:148-176, PitchProcess.cpp:76-100)
+    ns.update(dict(key=key, p=15, f_min=100, f_max=800, valley=True, w_len=1024, overlap=256 / 1024, hop=768, delta=0.94, yin_tol=0.25,
+                   f_s=FS, tau_max=int(np.ceil(FS / 100))))
+    ns["notes_freq"], ns["notes_str"] = ns["build_notes_vector"](key)
+    exec("\n".join(l for l in cells[7].split("\n") if not l.strip().startswith("plt.")), ns)     # cell 7: st_window (plots dropped)
+    exec(cells[9], ns)                                                                             # cell 9: def pitch_corrector
+    # the loop's per-frame intermediate results, recorded as its own calls into methods.py return them
+    ns["_rec"] = {"an": [], "st": [], "beta": []}
+    for fn, slot in (("pitch_marks", "an"), ("synthesis_pitch_marks", "st")):
+        def wrap(f, slot=slot):
+            def g(*a, **k):
+                r = f(*a, **k)
+                ns["_rec"][slot].append(np.array(r, dtype=np.int64).copy())
+                if slot == "st":
+                    ns["_rec"]["beta"].append(float(a[5]))
+                return r
+            return g
+        ns[fn] = wrap(ns[fn])
+    return ns
+
+
+def voiced_stream(seed, n, f0, vibrato=0.004, harmonics=10):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / FS
+    ph = 2 * np.pi * np.cumsum(f0 * (1 + vibrato * np.sin(2 * np.pi * 5.0 * t))) / FS
+    x = sum(np.sin(h * ph + rng.uniform(0, 2 * np.pi)) / h for h in range(1, harmonics + 1)) * 0.22
+    x = x + rng.normal(0, 0.002, n)
+    return x.astype(np.float32)
+
+
+def main():
+    out = {}
+    D = 441 + 1024 - 768
+    n = 1024 * 22
+    # (beta below and above 1; fundamentals for which the notebook's int() and the plugin's round() of period / beta agree on
+    # most frames -- the test only compares stretches where they do, and counts the rest)
+    cases = [("sharp_234_beta_lt_1", "Chrom", 233.9, 1), ("flat_191_beta_gt_1", "Chrom", 191.5, 2), ("low_151", "Chrom", 151.0, 3),
+             ("key_C_207", "C", 207.0, 6), ("key_F_300_beta_lt_1", "F", 300.0, 7), ("key_F_344", "F", 344.0, 8)]
+    names = []
+    for name, key, f0, seed in cases:
+        ns = notebook_namespace(key if key != "Chrom" else "chromatic")
+        x = voiced_stream(seed, n, f0)
+        xn = np.concatenate([np.zeros(D), x.astype(np.float64)])
+        y, pitch_arr = ns["pitch_corrector"](xn, 1024, 768, ns["st_window"], key, 0.94, 0.25, True, FS, 100, 800)
+        out[f"{name}_x"] = x
+        out[f"{name}_y"] = y.astype(np.float32)          # (the plugin's own output is float32)
+        out[f"{name}_pitch"] = pitch_arr
+        for slot in ("an", "st"):
+            m = np.full((len(ns["_rec"][slot]), 24), -999, dtype=np.int16)
+            for i_, r in enumerate(ns["_rec"][slot]):
+                m[i_, :len(r)] = r
+            out[f"{name}_{slot}_marks"] = m
+        out[f"{name}_beta"] = np.array(ns["_rec"]["beta"])
+        out[f"{name}_key"] = np.array(key)
+        names.append(name)
+        print(name, "pitch median", np.median(pitch_arr[pitch_arr > 10]), "rms out", np.sqrt(np.mean(y[4096:-4096] ** 2)))
+    out["names"] = np.array(names)
+    out["delay"] = np.array(D)
+    out["shift"] = np.array(-1024 + D)
+    np.savez_compressed(os.path.join(HERE, "pitch_corrector_vectors.npz"), **out)
+    print("wrote", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -420,10 +420,10 @@ def test_batched_vocoder_pipeline_fast_mode_per_stream_orders_and_auto_selection
             else:
                 assert np.sqrt(np.mean((got[s_].astype(np.float64) - want) ** 2)) < 1e-4, s_
         p.setStreamParameter(5, "lpcVoice", 64)                      # above the pipeline's orders: the workgroup kernel again
-        assert p.vocoder_kernel_name() in ("vp_k_vocoder", "vp_k_vocoder_lite")
+        assert p.vocoder_kernel_name() in ("vp_k_vocoder", "vp_k_vocoder_o48", "vp_k_vocoder_lite")
     q = BatchVocoderProcessor()
     q.prepareToPlay(FS, N, 100)
-    assert q.vocoder_kernel_name() == "vp_k_vocoder"
+    assert q.vocoder_kernel_name() == "vp_k_vocoder_o48"                # default lpcVoice 40: the build for orders 33..48
 
 
 @pytest.mark.parametrize("S,path", [(6, "batched"), (1024, "auto")])

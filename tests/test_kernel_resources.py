@@ -1,0 +1,50 @@
+"""CPU-side check of the built library's code objects (no GPU, no compiler run): the kernels that the BASELINE configs launch
+must not use scratch memory -- a spilled register in a serial phase is a memory round trip, and 428 bytes per lane of it was
+35 MB of traffic per launch in round 2.  The figures come from the AMDGPU metadata notes of
+libvp_amd.so (tools/kernel_resources.py)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# what `python bench.py` (configs[1] + the configs2/3/4 legs, FAST and EXACT IIR) launches
+BASELINE_KERNELS = [
+    "vp_k_pitch_fast_c", "vp_k_pitch_c",                      # configs[1]: 256 streams, pitch corrector (FAST / bit-exact)
+    "vp_k_vocoder",                                           # configs[2]: 256 streams, vocoder, LPC order 24
+    "vp_k_pitch_lite_fast_c", "vp_k_v2_ingest_stage", "vp_k_v2_autocorr<4>", "vp_k_v2_autocorr<8>", "vp_k_v2_levinson2<40, 8>",
+    "vp_k_v2_fir2<40, 8>", "vp_k_v2_energy_slices", "vp_k_v2_iir_fast<3, 1>", "vp_k_v2_ola",               # configs[3]
+    "vp_k_pitch_fast", "vp_k_v2_levinson2<48, 32>", "vp_k_v2_fir2<48, 32>",                                  # configs[4] geometry
+    "vp_k_pitch_fast_multi_c", "vp_k_emit", "vp_k_ingest_gate",
+]
+
+
+@pytest.fixture(scope="module")
+def resources():
+    from vocoderproject_amd import build
+    import kernel_resources
+    if not os.path.exists(os.path.join(kernel_resources.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    return kernel_resources.kernel_resources(build.build())
+
+
+def test_metadata_lists_the_kernels(resources):
+    assert len(resources) > 40
+    for k in BASELINE_KERNELS:
+        assert k in resources, f"{k} not found in the code objects: {sorted(resources)[:8]} ..."
+
+
+def test_no_scratch_in_the_kernels_the_baseline_configs_launch(resources):
+    bad = {k: resources[k]["scratch"] for k in BASELINE_KERNELS if resources[k]["scratch"] > 0}
+    assert not bad, f"kernels with scratch (bytes per lane): {bad}"
+
+
+def test_occupancy_two_for_the_full_register_builds(resources):
+    """512-thread workgroups need two wavefronts per SIMD: VGPRs + AGPRs must stay within 256."""
+    for k in ("vp_k_pitch_fast_c", "vp_k_pitch_c", "vp_k_pitch_fast", "vp_k_vocoder", "vp_k_vocoder_o48"):
+        r = resources[k]
+        assert r["vgpr"] + r["agpr"] <= 256, (k, r)
+    for k in ("vp_k_pitch_lite_fast_c", "vp_k_vocoder_lite"):
+        assert resources[k]["vgpr"] + resources[k]["agpr"] <= 128, (k, resources[k])

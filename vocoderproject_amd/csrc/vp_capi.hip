@@ -169,6 +169,9 @@ static bool voc_batched_for(const vp_handle *h, int nStreams, int nWin, int oV, 
 }
 static bool voc_batched(const vp_handle *h, int nStreams, int nWin) { return voc_batched_for(h, nStreams, nWin, h->oVmax, h->oSmax); }
 
+// the workgroup vocoder's two full-register builds: vp_k_vocoder (orders up to 32, and above 48: no scratch) and vp_k_vocoder_o48
+static bool voc_o48(const vp_handle *h) { return h->oVmax > 32 && h->oVmax <= 48; }
+
 extern "C" int vp_set_vocoder_path(vp_handle *h, int path)
 {
     if (!h || path < VP_VOC_AUTO || path > VP_VOC_BATCHED) return VP_ERR_INVALID_ARG;
@@ -192,7 +195,10 @@ extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
         for (const auto &q : h->sparams) { oV = std::max(oV, q.lpcVoice); oS = std::max(oS, q.lpcSynth); }
         if (voc_batched_for(h, h->g.S, h->nWinMax, oV, oS)) return "vp_k_v2_pipeline";      // (orders as the next block will see them)
     }
-    return voc_lite_slots(h, h->iirMode == VP_IIR_FAST, h->vocWaves) ? "vp_k_vocoder_lite" : "vp_k_vocoder";
+    if (voc_lite_slots(h, h->iirMode == VP_IIR_FAST, h->vocWaves)) return "vp_k_vocoder_lite";
+    int oV = 0;
+    for (const auto &q : h->sparams) oV = std::max(oV, q.lpcVoice);
+    return (oV > 32 && oV <= 48) ? "vp_k_vocoder_o48" : "vp_k_vocoder";
 }
 
 extern "C" const char *vp_kernel_slot_name(int slot)
@@ -550,7 +556,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c,
-                             (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_lite};
+                             (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
             HIPCHK(h, hipFuncGetAttributes(&fa, f));                        // the static part (a few reduction slots) comes off the top
@@ -858,7 +864,9 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cv.ldsBytes = (int)vp_voc_lds_bytes(g.W, nw);
                 cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
                 const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
-                hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : vp_k_vocoder, dim3(co.n), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st, g, cv, d, d_in, d_out);
+                // (orders 33..48: the build that carries the big register-resident instantiations, see vp_vocoder_wg.inc)
+                hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : voc_o48(h) ? vp_k_vocoder_o48 : vp_k_vocoder, dim3(co.n), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st,
+                                   g, cv, d, d_in, d_out);
             }
             if (runPitch && !runPitchDone) {
                 VpCall cp = c;

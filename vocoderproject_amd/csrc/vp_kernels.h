@@ -6,6 +6,7 @@
 
 __global__ void vp_k_ingest_gate(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in);
 __global__ void vp_k_vocoder(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_vocoder_o48(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_vocoder_lite(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_lite(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);

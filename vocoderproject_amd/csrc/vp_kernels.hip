@@ -158,7 +158,7 @@ __device__ __forceinline__ double wave_sum(double v)
 __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in,
                                                   int boff = 0)
 {
-    const int s = vp_stream(d), tid = threadIdx.x, nt = blockDim.x;
+    const int s = vp_stream(d), tid = vp_tid(), nt = blockDim.x;
     float *vr = d.voiceRing + (size_t)s * g.inSize;
     float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     float *sr1 = sr0 + g.inSize;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
     const int dryOn = stl ? stl->sp.dryOn : d.pitch[s].sp.dryOn, synthOn = stl ? stl->sp.synthOn : d.pitch[s].sp.synthOn;
     const double gainVoice = stl ? stl->sp.gainVoice : d.pitch[s].sp.gainVoice;
     const double gainSynth = stl ? stl->sp.gainSynth : d.pitch[s].sp.gainSynth;
-    for (int i = threadIdx.x; i < g.N; i += blockDim.x) {
+    for (int i = vp_tid(); i < g.N; i += blockDim.x) {
         int pos = (c.outCounter + boff + i) % g.outSize;
         int pin = (c.currCounter + boff + i) % g.inSize;
         double v = oA ? oA[i] : acc[pos];
