@@ -40,7 +40,8 @@ enum {
 
 /* The ten plugin parameters, same ids, ranges and defaults as
  * VocoderAudioProcessor::createParameterLayout() (PluginProcessor.cpp:37-73).
- * They apply to every stream of the handle. */
+ * vp_set_params() gives every stream of the handle this set; vp_set_stream_params() gives ONE stream its own (each stream
+ * of a batch is a plugin instance with its own treeState), all ten parameters except lpcPitch. */
 typedef struct vp_params {
     float gainPitch;   /* dB  [-60, 6]   default   0 */
     float gainVoice;   /* dB  [-60, 6]   default -60 (dry voice off) */
@@ -78,10 +79,11 @@ int vp_destroy(vp_handle *h);
 int vp_set_params(vp_handle *h, const vp_params *p);
 int vp_get_params(const vp_handle *h, vp_params *p);
 /* One parameter set PER STREAM (each stream of a batch is its own plugin instance with its own treeState).
- * After prepare; takes effect at the next block.  pitchBool, vocBool and lpcPitch stay per handle (they drive the
- * block's kernel plan and the prepare-time geometry): `p` must repeat the handle's values for them
- * (VP_ERR_INVALID_ARG otherwise).  A later vp_set_params() puts every stream back on one common set;
- * so does a new prepare. */
+ * After prepare; takes effect at the next block.  Everything is per stream, pitchBool and vocBool included: a process that
+ * is switched off does not advance its startSample / nChunk (PluginProcessor.cpp:214-221), so the library keeps streams
+ * whose switches differ(ed) as separate cohorts and launches each with a stream-index map.  Only lpcPitch stays per handle
+ * (it is read at prepare and selects the pitch kernel's build): `p` must repeat the handle's value for it
+ * (VP_ERR_INVALID_ARG otherwise).  A later vp_set_params() puts every stream back on one common set; so does a new prepare. */
 int vp_set_stream_params(vp_handle *h, int stream, const vp_params *p);
 int vp_get_stream_params(const vp_handle *h, int stream, vp_params *p);
 void vp_default_params(vp_params *p);
@@ -215,7 +217,10 @@ const char *vp_kernel_slot_name(int slot);
 /* Symbol of the pitch-kernel build the handle's current geometry and modes select (slot 2 is one of
  * vp_k_pitch[_fast][_c], vp_k_pitch_lite[_fast], vp_k_pitch[_fast]_fft; _c = the common-case builds); "" before prepare. */
 const char *vp_pitch_kernel_name(const vp_handle *h);
-/* Likewise for slot 1: vp_k_vocoder, or vp_k_vocoder_lite (FAST IIR, more than 256 streams: two workgroups per CU). */
+/* Likewise for slot 1: vp_k_vocoder (LPC orders up to 32 and above 48) / vp_k_vocoder_o48 (orders 33..48), vp_k_vocoder_lite
+ * (FAST IIR, more than 256 streams on the workgroup path: two workgroups per CU), or "vp_k_v2_pipeline" -- the lane-per-window
+ * pipeline of kernels (vp_k_v2_ingest_stage, _autocorr, _levinson2, _fir2, _energy[_slices], _iir_exact / _iir_fast, _ola) that
+ * VP_VOC_AUTO picks above 256 streams with at least 1024 windows per block. */
 const char *vp_vocoder_kernel_name(const vp_handle *h);
 
 /* Counts, over all streams since prepare, how often a kernel reached one of the reference's

@@ -300,6 +300,66 @@ def test_scatter_gather_over_nccl_world_size_1():
     _assert_equal(got, np.stack(ref), "nccl world 1")
 
 
+def _nccl_two_rank_worker(rank, world, port, S, N, B, ret):
+    import torch
+    import torch.distributed as dist
+    from vocoderproject_amd import BatchVocoderProcessor
+    from vocoderproject_amd.dist import exchange_steps, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (see bench.py)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        lo, hi = shard_range(S, rank, world)
+        p = BatchVocoderProcessor(device=rank)
+        p.prepareToPlay(FS, N, hi - lo)
+        st = torch.cuda.current_stream(dev)
+        xr = torch.from_numpy(_streams(S, N * B)).to(dev).view(S, 3, B, N).permute(2, 0, 1, 3).contiguous() if rank == 0 else None
+        outs = [torch.empty((S, 2, N), dtype=torch.float32, device=dev) for _ in range(B)] if rank == 0 else None
+        exchange_steps(B, S, (lambda i: xr[i]), (lambda i: outs[i]), (3, N), (2, N), torch.float32, dev,
+                       lambda i_, o_: p.process_device(i_, o_, st.cuda_stream))
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            ret["y"] = torch.stack(outs, 0).permute(1, 2, 0, 3).reshape(S, 2, B * N).cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_over_nccl_two_ranks():
+    """SURVEY 8(e) on real RCCL traffic: rank 0 holds the batch, two ranks (two GPUs) each process their shard per step,
+    double-buffered scatter / gather (dist.exchange_steps); the reassembled output must be the oracle's bit for bit.  Needs two
+    GPUs: skips itself on the one-GPU boxes this build has had (there the gloo tests and the world-size-1 test above cover
+    the same code)."""
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import oracle_py as O
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    S, N, B = 7, 1024, 8                                              # ragged shards: 4 + 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as man:
+        ret = man.dict()
+        procs = [ctx.Process(target=_nccl_two_rank_worker, args=(r, 2, port, S, N, B, ret)) for r in range(2)]
+        for q in procs:
+            q.start()
+        for q in procs:
+            q.join(600)
+        assert all(q.exitcode == 0 for q in procs), [q.exitcode for q in procs]
+        got = ret["y"]
+    x = _streams(S, N * B)
+    ref = []
+    for s_ in range(S):
+        o = O.OracleStream()
+        o.prepare_to_play(FS, N)
+        ref.append(o.run(x[s_]))
+    _assert_equal(got, np.stack(ref), "nccl two ranks")
+
+
 # ---- large batches from a cold start, certified-YIN fallback path -------------------------------------------------------
 
 @pytest.mark.parametrize("yin", ["xcorr", "xcorr_force_fallback"])
@@ -419,7 +479,27 @@ def test_batched_vocoder_pipeline_fast_mode_per_stream_orders_and_auto_selection
                 _assert_equal(got[s_], want, f"stream {s_}")
             else:
                 assert np.sqrt(np.mean((got[s_].astype(np.float64) - want) ** 2)) < 1e-4, s_
-        p.setStreamParameter(5, "lpcVoice", 64)                      # above the pipeline's orders: the workgroup kernel again
+        # one stream above the pipeline's orders: it becomes a cohort of its own on the workgroup kernel, the other 383 keep the
+        # pipeline (round 2 demoted the whole batch) -- and all of them still come out right
+        p.setStreamParameter(5, "lpcVoice", 64)
+        assert p.vocoder_kernel_name() == "vp_k_v2_pipeline"
+        x2 = np.ascontiguousarray(x[:, :, :N * 3])
+        got2 = _run_blocks(p, x2, N)
+        for s_ in (0, 5, 300):
+            o = O.OracleStream()
+            o.prepare_to_play(FS, N)
+            for k, v in per.get(s_, {}).items():
+                o.set_param(k, v)
+            want = o.run(x[s_])                                       # (the oracle stream replays the first B blocks with the old order ...)
+            if s_ == 5:
+                o.set_param("lpcVoice", 64)
+            want2 = o.run(x2[s_])                                     # ... then these three
+            if iir == "exact":
+                _assert_equal(got2[s_], want2, f"stream {s_} after one stream's order went to 64")
+            else:
+                assert np.sqrt(np.mean((got2[s_].astype(np.float64) - want2) ** 2)) < 1e-4, s_
+        for s_ in range(S):
+            p.setStreamParameter(s_, "lpcVoice", 64)                  # every stream above: nothing is left for the pipeline
         assert p.vocoder_kernel_name() in ("vp_k_vocoder", "vp_k_vocoder_o48", "vp_k_vocoder_lite")
     q = BatchVocoderProcessor()
     q.prepareToPlay(FS, N, 100)

@@ -29,6 +29,20 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version():
+    """`hipcc --version`, part of the object-cache key: an upgraded compiler at the same path must not be served stale objects."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+        except (OSError, subprocess.SubprocessError):
+            _HIPCC_VERSION = "unknown"
+    return _HIPCC_VERSION
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -76,7 +90,7 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             import hashlib
             src, obj, extra = job
             cmd = common + extra + ["-c", src, "-o", obj]
-            hsh = hashlib.sha256(" ".join(cmd[:-1]).replace(tmp, "").encode())
+            hsh = hashlib.sha256((hipcc_version() + " ".join(cmd[:-1]).replace(tmp, "")).encode())
             deps = {"vp_kernels.hip": ["vp_kernels.hip", "vp_common.h"] + PARTS,
                     "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"] + PARTS}.get(os.path.basename(src))
             if deps is None:
@@ -93,7 +107,9 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            shutil.copy(obj, cached)
+            part = cached + ".part%d" % os.getpid()                # (atomic: a concurrent build must never see half an object)
+            shutil.copy(obj, part)
+            os.replace(part, cached)
             return obj
 
         with ThreadPoolExecutor(len(jobs)) as ex:

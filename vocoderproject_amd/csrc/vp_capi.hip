@@ -34,7 +34,9 @@ struct vp_handle {
     // is on (PluginProcessor.cpp:214-221), so streams whose switches differ(ed) carry different values: the batch is
     // kept as COHORTS of streams that share switches and counters.  One cohort holding every stream (dMap == nullptr)
     // is the normal case and costs nothing; otherwise each cohort is launched on its own with a stream-index map.
-    struct Cohort { int pitchOn, vocOn, vStart, pStart, nChunk, n; int *dMap; std::vector<int> ids; };
+    // ordHi: the cohort's streams ask for a voice LPC order above what the lane-per-window pipeline is instantiated for (they
+    // take the workgroup kernel; the others keep the pipeline: one order-64 stream no longer demotes a thousand others)
+    struct Cohort { int pitchOn, vocOn, vStart, pStart, nChunk, n; int *dMap; std::vector<int> ids; int ordHi = 0, oVmax = 0, oSmax = 0; };
     std::vector<Cohort> cohorts;
     bool cohortsDirty = false;                  // a set call changed some stream's pitchBool / vocBool
     int *dMapAll = nullptr;                     // [S] device storage of the cohorts' maps, back to back
@@ -161,16 +163,26 @@ static int voc_lite_slots(const vp_handle *h, bool iirFast, int nw)
 // windows per stream.  VP_VOC_BATCHED forces it wherever it is able to run.
 #define VP_V2_MIN_STREAMS 257
 #define VP_V2_MIN_WINDOWS 1024
-static bool voc_batched_for(const vp_handle *h, int nStreams, int nWin, int oV, int oS)
+// VP_VOC_AUTO is decided ONCE per prepare from the handle's batch (streams x windows per block), not per block and cohort: a
+// cohort split (one stream's pitchBool toggled) or a block with one window fewer (N not a multiple of the hop) must not flip
+// the other streams between the two implementations, whose FAST-mode roundings differ.
+static bool voc_auto_batched(const vp_handle *h)
 {
-    if (!h->v2.xT || h->vocPath == VP_VOC_WORKGROUP || nWin < 1 || nWin > 64) return false;
-    if (oV > V2_ORDER_MAX || oS > VP_ORDER_MAX_SYNTH || oV < 2 || oS < 2) return false;
-    return h->vocPath == VP_VOC_BATCHED || (nStreams >= VP_V2_MIN_STREAMS && (size_t)nStreams * nWin >= VP_V2_MIN_WINDOWS);
+    return h->g.S >= VP_V2_MIN_STREAMS && (size_t)h->g.S * h->nWinMax >= VP_V2_MIN_WINDOWS;
 }
-static bool voc_batched(const vp_handle *h, int nStreams, int nWin) { return voc_batched_for(h, nStreams, nWin, h->oVmax, h->oSmax); }
+static bool voc_pipeline_wanted(const vp_handle *h)
+{
+    return h->v2.xT && h->vocPath != VP_VOC_WORKGROUP && (h->vocPath == VP_VOC_BATCHED || voc_auto_batched(h));
+}
+// per block only what the pipeline is ABLE to run: orders it is instantiated for, 1..64 windows per stream
+static bool voc_batched_for(const vp_handle *h, int nWin, int oV, int oS)
+{
+    if (!voc_pipeline_wanted(h) || nWin < 1 || nWin > 64) return false;
+    return oV <= V2_ORDER_MAX && oS <= VP_ORDER_MAX_SYNTH && oV >= 2 && oS >= 2;
+}
 
 // the workgroup vocoder's two full-register builds: vp_k_vocoder (orders up to 32, and above 48: no scratch) and vp_k_vocoder_o48
-static bool voc_o48(const vp_handle *h) { return h->oVmax > 32 && h->oVmax <= 48; }
+static bool voc_o48(int oVmax) { return oVmax > 32 && oVmax <= 48; }
 
 extern "C" int vp_set_vocoder_path(vp_handle *h, int path)
 {
@@ -191,9 +203,11 @@ extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
     {
-        int oV = 0, oS = 0;
-        for (const auto &q : h->sparams) { oV = std::max(oV, q.lpcVoice); oS = std::max(oS, q.lpcSynth); }
-        if (voc_batched_for(h, h->g.S, h->nWinMax, oV, oS)) return "vp_k_v2_pipeline";      // (orders as the next block will see them)
+        // (orders as the next block will see them; streams above the pipeline's orders form a cohort of their own on the workgroup
+        // kernel, the others keep the pipeline)
+        int oV = 0, oS = 0, nLow = 0;
+        for (const auto &q : h->sparams) if (q.lpcVoice <= V2_ORDER_MAX) { oV = std::max(oV, q.lpcVoice); oS = std::max(oS, q.lpcSynth); nLow++; }
+        if (nLow > 0 && voc_batched_for(h, h->nWinMax, oV, oS)) return "vp_k_v2_pipeline";
     }
     if (voc_lite_slots(h, h->iirMode == VP_IIR_FAST, h->vocWaves)) return "vp_k_vocoder_lite";
     int oV = 0;
@@ -702,10 +716,10 @@ static void fill_stream_params(VpStreamParams &o, const vp_params &P)
 static int rebuild_cohorts(vp_handle *h, hipStream_t st)
 {
     const int S = h->g.S;
-    struct Key { int pitchOn, vocOn, vStart, pStart, nChunk; };
+    struct Key { int pitchOn, vocOn, vStart, pStart, nChunk, ordHi; };
     std::vector<Key> cur((size_t)S);
     for (const auto &co : h->cohorts) {
-        const Key k{co.pitchOn, co.vocOn, co.vStart, co.pStart, co.nChunk};
+        const Key k{co.pitchOn, co.vocOn, co.vStart, co.pStart, co.nChunk, co.ordHi};
         if (!co.dMap) for (int i = 0; i < S; i++) cur[i] = k;
         else for (int i : co.ids) cur[i] = k;
     }
@@ -713,11 +727,13 @@ static int rebuild_cohorts(vp_handle *h, hipStream_t st)
     for (int i = 0; i < S; i++) {
         Key k = cur[i];
         k.pitchOn = h->sparams[i].pitchBool; k.vocOn = h->sparams[i].vocBool;
+        k.ordHi = (voc_pipeline_wanted(h) && k.vocOn && h->sparams[i].lpcVoice > V2_ORDER_MAX) ? 1 : 0;
         vp_handle::Cohort *hit = nullptr;
         for (auto &co : out)
-            if (co.pitchOn == k.pitchOn && co.vocOn == k.vocOn && co.vStart == k.vStart && co.pStart == k.pStart && co.nChunk == k.nChunk) { hit = &co; break; }
-        if (!hit) { out.push_back(vp_handle::Cohort{k.pitchOn, k.vocOn, k.vStart, k.pStart, k.nChunk, 0, nullptr, {}}); hit = &out.back(); }
+            if (co.pitchOn == k.pitchOn && co.vocOn == k.vocOn && co.vStart == k.vStart && co.pStart == k.pStart && co.nChunk == k.nChunk && co.ordHi == k.ordHi) { hit = &co; break; }
+        if (!hit) { out.push_back(vp_handle::Cohort{k.pitchOn, k.vocOn, k.vStart, k.pStart, k.nChunk, 0, nullptr, {}}); out.back().ordHi = k.ordHi; hit = &out.back(); }
         hit->ids.push_back(i);
+        hit->oVmax = std::max(hit->oVmax, h->sparams[i].lpcVoice); hit->oSmax = std::max(hit->oSmax, h->sparams[i].lpcSynth);
     }
     if (out.size() == 1) { out[0].ids.clear(); out[0].n = S; out[0].dMap = nullptr; }
     else {
@@ -751,6 +767,9 @@ static int sync_stream_state(vp_handle *h, hipStream_t st)
         HIPCHK(h, hipMemcpy2DAsync(&h->d.pitch[0].sp, sizeof(VpPitchState), h->spHost.data(), sizeof(VpStreamParams),
                                    sizeof(VpStreamParams), (size_t)g.S, hipMemcpyHostToDevice, st));
         h->spDirty = false;
+        // the cohorts carry their own order maxima (and are keyed by the order class when the pipeline is in play)
+        if (h->cohorts.size() == 1 && !h->perStream) { h->cohorts[0].oVmax = h->oVmax; h->cohorts[0].oSmax = h->oSmax; if (h->cohorts[0].ordHi) h->cohortsDirty = true; }
+        else h->cohortsDirty = true;
     }
     if (h->cohortsDirty) return rebuild_cohorts(h, st);
     return VP_OK;
@@ -809,7 +828,8 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             { ProfScope ps(h, st, 0); hipLaunchKernelGGL(vp_k_ingest_gate, dim3(co.n), dim3(256), 0, st, g, c, d, d_in); }
             { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, d, d_out); }
         } else {
-            if (runVoc && runPitch && c.iirFast && h->overlap && nBlocks == 1 && voc_batched(h, co.n, c.nWin)) {
+            const bool batched = runVoc && voc_batched_for(h, c.nWin, co.oVmax, co.oSmax);
+            if (batched && runPitch && c.iirFast && h->overlap && nBlocks == 1) {
                 // VP_IIR_FAST (tolerance mode), both processes, batched vocoder: the pitch kernel starts on a second HIP stream
                 // as soon as the input is in the rings and the gate is known, and adds into an accumulator of its own; the
                 // vocoder pipeline's serial stages occupy few SIMDs, the pitch kernel's serial phases leave issue slots free.
@@ -832,7 +852,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 VpCall cv = c;
                 cv.fuseIngest = 1; cv.fuseEmit = 0;
                 VpV2 v = h->v2;
-                v.nStreams = co.n; v.oVmax = h->oVmax; v.oSmax = h->oSmax;
+                v.nStreams = co.n; v.oVmax = co.oVmax; v.oSmax = co.oSmax;
                 { ProfScope ps(h, st, 1); vp_v2_launch(g, cv, d, v, d_in, d_out, st, fork, &fk); }
                 if (fk.err != hipSuccess) return fail_hip(h, fk.err, "fork of the pitch kernel");
                 HIPCHK(h, hipEventRecord(h->evJoin, h->auxStream));
@@ -842,13 +862,13 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, de, d_out); }
                 h->acc2Live = (g.outSize + g.N - 1) / g.N + 1;               // (+1: this block's own decrement below)
                 runPitchDone = true;
-            } else if (runVoc && voc_batched(h, co.n, c.nWin)) {
+            } else if (batched) {
                 // large batches: the pipeline of lane-per-window kernels (vp_voc2.hip), ingest+gate in front, emit behind
                 VpCall cv = c;
                 cv.fuseIngest = 1; cv.fuseEmit = runPitch ? 0 : 1;
                 ProfScope ps(h, st, 1);
                 VpV2 v = h->v2;
-                v.nStreams = co.n; v.oVmax = h->oVmax; v.oSmax = h->oSmax;
+                v.nStreams = co.n; v.oVmax = co.oVmax; v.oSmax = co.oSmax;
                 vp_v2_launch(g, cv, d, v, d_in, d_out, st);
             } else if (runVoc) {
                 VpCall cv = c;
@@ -865,7 +885,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cv.vocWin = nw;                                   // window slots per round; spare wavefronts (up to as many again) help
                 const int nThreads = 64 * nw * std::max(1, 8 / nw);           // a whole number of wavefronts per window slot, at most 8
                 // (orders 33..48: the build that carries the big register-resident instantiations, see vp_vocoder_wg.inc)
-                hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : voc_o48(h) ? vp_k_vocoder_o48 : vp_k_vocoder, dim3(co.n), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st,
+                hipLaunchKernelGGL(lite ? vp_k_vocoder_lite : voc_o48(co.oVmax) ? vp_k_vocoder_o48 : vp_k_vocoder, dim3(co.n), dim3(nThreads), vp_voc_lds_bytes(g.W, nw), st,
                                    g, cv, d, d_in, d_out);
             }
             if (runPitch && !runPitchDone) {
@@ -967,7 +987,9 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX) return VP_OK;
     auto &co = h->cohorts[0];
     if (!co.vocOn || co.pitchOn || !h->v2.xT || h->vocPath == VP_VOC_WORKGROUP) return VP_OK;
-    if (h->oVmax > V2_ORDER_MAX || h->oSmax > VP_ORDER_MAX_SYNTH || h->oVmax < 2 || h->oSmax < 2) return VP_OK;
+    if (co.oVmax > V2_ORDER_MAX || co.oSmax > VP_ORDER_MAX_SYNTH || co.oVmax < 2 || co.oSmax < 2) return VP_OK;
+    // vp_k_v2_mb_ola_emit keeps outSize doubles in dynamic LDS: a geometry beyond its ceiling takes the block-by-block plan
+    if ((size_t)g.outSize * sizeof(double) > (size_t)VP_V2_MB_LDS_MAX) return VP_OK;
     VpV2MB mb;
     memset(&mb, 0, sizeof mb);
     mb.nBlocks = nb;
@@ -995,7 +1017,7 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     d.streamMap = co.dMap;
     d.outAcc2 = h->acc2Live > 0 ? h->acc2 : nullptr;
     VpV2 v = h->v2mb;
-    v.nStreams = co.n; v.oVmax = h->oVmax; v.oSmax = h->oSmax;
+    v.nStreams = co.n; v.oVmax = co.oVmax; v.oSmax = co.oSmax;
     { ProfScope ps(h, st, 1); vp_v2_launch_blocks(g, c, d, v, mb, d_in, d_out, st); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->poisoned = true; return fail_hip(h, e, "kernel launch"); }

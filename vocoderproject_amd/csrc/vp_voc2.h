@@ -30,6 +30,7 @@ struct VpV2 {
 
 // multi-block launches (vp_process_blocks_device, vocoder-only plan): per block of the launch
 #define V2_MB_MAX 16
+#define VP_V2_MB_LDS_MAX (160 * 1024 - 1024)      // dynamic-LDS ceiling vp_v2_init() sets on vp_k_v2_mb_ola_emit (it holds outSize doubles)
 struct VpV2MB { int nBlocks, vStart[V2_MB_MAX], nWin[V2_MB_MAX], first[V2_MB_MAX]; };
 
 int vp_v2_init();

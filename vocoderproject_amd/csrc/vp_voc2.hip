@@ -743,7 +743,7 @@ template <int P> static void v2_launch_iir_exact(dim3 grid, hipStream_t st, cons
 
 int vp_v2_init()
 {
-    if (hipFuncSetAttribute((const void *)vp_k_v2_mb_ola_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)vp_k_v2_mb_ola_emit, hipFuncAttributeMaxDynamicSharedMemorySize, VP_V2_MB_LDS_MAX) != hipSuccess) return -1;
     // dynamic-LDS ceilings of the two kernels that use it (process-wide function attributes)
     return 0;
 }

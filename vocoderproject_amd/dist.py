@@ -90,7 +90,14 @@ def exchange_steps(n_steps, n_streams, in_root, out_root, in_tail, out_tail, dty
     ranks, every rank runs `process(in_shard, out_shard)` on its own shard, the root gathers [n_streams, *out_tail] into
     `out_root(i)` (root only; may return None to let the helper allocate).  Step i+1's scatter and step i-1's gather are in
     flight while step i is processed.  Returns the list of the root's output tensors of the last two steps (root) or None.
-    Every rank must call it with the same n_steps."""
+    Every rank must call it with the same n_steps.
+
+    STREAM CONTRACT: `process` must enqueue its work on torch's CURRENT stream of `device` (pass
+    `torch.cuda.current_stream(device).cuda_stream` to process_device): the double buffering is ordered against the kernels only
+    through NCCL's implicit synchronisation with the current stream (`w.wait()` makes the current stream wait for the transfer,
+    and a transfer is enqueued behind whatever the current stream holds).  A `process` that launches on a stream of its own
+    races the scatter of step i + 1 into the other input buffer's twin and the reuse of its output buffer.  To run the whole
+    exchange on another stream, call this function under `with torch.cuda.stream(that_stream):`."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_streams, rank, world)
     inb = [torch.empty((hi - lo, *in_tail), dtype=dtype, device=device) for _ in range(2)]
