@@ -21,6 +21,9 @@
 // Every kernel is bit-identical to vp_k_vocoder in VP_IIR_EXACT mode (tests/test_gpu_round2.py); in VP_IIR_FAST mode the
 // recursion is the block form the pitch kernel uses (tolerance-tested).  Citations: file:line under /root/reference/Source/.
 #define VP_TU 99                 // vp_kernels.hip's device helpers without any of its kernels
+#ifndef VP_V2_AC_WIN_LDS
+#define VP_V2_AC_WIN_LDS 0
+#endif
 #include "vp_kernels.hip"
 
 #include <algorithm>
@@ -151,6 +154,15 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         // loop iteration, the second one half a ring further on), eight new ones per trip; those and the eight samples of
         // tmp = x[n] w[n] are requested one trip ahead (aligned 16-byte loads, contiguous across the lanes; the last trip
         // reads a few samples past the window: inside the tile's padding, never used).
+        // (round 3) the window function of the main loop through SCALAR loads: every index is wave-uniform and inside [0, W), so the
+        // values arrive in SGPRs and feed the multiplies as their one scalar operand -- the loop then holds no LDS instruction at
+        // all (19 broadcast reads per 8-element trip at ~8 ns of issue each were 40 % of the trip).  VP_V2_AC_WIN_LDS=1: the LDS copy.
+#if VP_V2_AC_WIN_LDS
+#define V2_AC_WIN(I) wl[I]
+#else
+        const double *__restrict__ wg = d.vocWin;
+#define V2_AC_WIN(I) wg[I]
+#endif
         double R[16];
 #pragma unroll
         for (int t = 0; t < L; t++) R[t] = (double)x[m0 + t];
@@ -161,9 +173,9 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         const float fx_[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w}, fu_[8] = {U0.x, U0.y, U0.z, U0.w, U1.x, U1.y, U1.z, U1.w}; \
         _Pragma("unroll") for (int t = 0; t < 8; t++) R[(L + t + PH) & 15] = (double)fx_[t]; \
         double u[8]; \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * wl[(N) + t];                 /* tmp, LPC.cpp:61 */ \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * V2_AC_WIN((N) + t);          /* tmp, LPC.cpp:61 */ \
         _Pragma("unroll") for (int t = 0; t < 8; t++) { \
-            _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * R[(t + j + PH) & 15]; p = p * wl[(N) + t + m0 + j]; sum[j] += p; } } }
+            _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * R[(t + j + PH) & 15]; p = p * V2_AC_WIN((N) + t + m0 + j); sum[j] += p; } } }
         // (requests run TWO trips ahead -- four named buffer sets, four trips per loop iteration: with one or two wavefronts
         // per SIMD a trip of 0.2-0.4 us does not cover a memory round trip)
         V2_AC_LOAD(au0, au1, ax0, ax1, 0)
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         }
 #undef V2_AC_LOAD
 #undef V2_AC_TRIP
+#undef V2_AC_WIN
     }
     for (int n = nMain; n < W - m0; n++) {                                  // the last steps: lags drop out one by one
         const double u = (double)x[n] * wl[n];
@@ -345,6 +358,9 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
 // The voice's and the side chain's coefficient / residual kernels are ONE launch each (blockIdx.y resp. blockIdx.z selects;
 // the side chain's orders are much smaller -- its own template parameter -- and its wavefronts fill in beside the voice's
 // instead of queueing behind them: 34 -> 24 us and 22 -> 18 us at 1024 streams).
+// (round 3, measured and dropped: the two sums of an order step with four partial accumulators each in VP_IIR_FAST mode -- no gain,
+// 18.4 us either way at order 40: the fully unrolled recursion is ~8000 instructions executed once per wavefront, bound by
+// instruction fetch, not by the sums' dependent chains)
 template <int PV, int PS>
 __global__ __launch_bounds__(64) void vp_k_v2_levinson2(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
