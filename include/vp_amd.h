@@ -173,6 +173,16 @@ int vp_get_vocoder_path(const vp_handle *h);
  * exact mode never does this.  A caller's hip_stream is respected: the work it sees is ordered on that stream. */
 int vp_set_overlap(vp_handle *h, int on);
 int vp_get_overlap(const vp_handle *h);
+/* SURVEY 8(f2), time-parallel pitch front end (off by default).  With the switch on, a multi-block call (vp_process_blocks[_mono]_device,
+ * pitch corrector only) first runs vp_k_pitch_front: yin() (PitchProcess.cpp:350-448) and the frame's LPC (LPC.cpp:44-148) for EVERY
+ * frame that starts inside the call, one workgroup per (stream, frame) -- both depend on the input alone --, and the serial kernel then
+ * reads a record per frame and goes straight to the marks.  Same routines, same modes, same bits as the block-by-block path
+ * (tests/test_gpu_round3.py).  Measured: the serial kernel drops from 58 to 42 us per block at 256 streams,
+ * the front end costs 15 us per block -- its cross-correlations are the same VALU work on the same CUs --, a wash at 256 streams
+ * and a loss above, hence not the default.  Needs the plugin-like geometry (frame a multiple of 64 samples, tauMax <= 512,
+ * lpcPitch < 64); ignored otherwise. */
+int vp_set_time_parallel(vp_handle *h, int on);
+int vp_get_time_parallel(const vp_handle *h);
 
 /* How the YIN difference function (PitchProcess.cpp:350-403) and the pitch frame's LPC autocorrelation
  * (LPC.cpp:44-97) are evaluated.

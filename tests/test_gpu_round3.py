@@ -1,0 +1,76 @@
+"""GPU tests added in round 3 (through the C ABI, against the CPU oracle or against the block-by-block path)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FS = 44100.0
+
+
+def _streams(S, T, **kw):
+    from vocoderproject_amd.synth import make_streams
+    return np.ascontiguousarray(make_streams(S, T, **kw).numpy())
+
+
+def _oracle(x, N, params):
+    from oracle import oracle_py as O
+    outs = []
+    for s in range(x.shape[0]):
+        o = O.OracleStream(**params)
+        o.prepare_to_play(FS, N)
+        outs.append(o.run(x[s]))
+    return np.stack(outs)
+
+
+@pytest.mark.parametrize("S,N,B,iir,yin", [(6, 1024, 8, "exact", "direct"), (6, 1024, 8, "exact", "xcorr"), (5, 1024, 3, "fast", "xcorr"),
+                                           (4, 256, 7, "exact", "xcorr"), (300, 1024, 8, "fast", "xcorr"), (7, 2048, 2, "exact", "xcorr")])
+def test_time_parallel_front_end_equals_block_by_block(S, N, B, iir, yin):
+    """with vp_set_time_parallel on, a multi-block pitch-only call computes yin() and the LPC of every frame that starts
+    inside it in vp_k_pitch_front (a workgroup per stream and frame) and the serial kernel consumes the records.  Same routines,
+    same modes: the output must be the block-by-block path's bit for bit (and, in the exact modes, the oracle's), over gate
+    crossings, cold starts, frames that straddle calls, blocks shorter than a frame, and the register-light builds above 256
+    streams."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    calls = 3
+    T = N * B * calls
+    U = min(S, 6)
+    base = _streams(U, T)
+    base[0, 0] *= np.where((np.arange(T) // 7000) % 2 == 0, 1.0, 1e-5).astype(np.float32)          # gate crossings
+    if U > 2:
+        base[2, 0, :N * 3] = 0                                                                     # a silent start
+    x = np.ascontiguousarray(base[np.arange(S) % U])
+
+    def run(tp):
+        p = BatchVocoderProcessor(vocBool=0)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode(iir)
+        p.set_yin_mode(yin)
+        p.set_time_parallel(tp)
+        xs = torch.from_numpy(x).cuda().view(S, 3, calls * B, N).permute(2, 0, 1, 3).contiguous()
+        ys = []
+        for i in range(calls):
+            y = torch.empty((B, S, 2, N), dtype=torch.float32, device="cuda")
+            if tp is None:
+                for b in range(B):
+                    p.process_device(xs[i * B + b], y[b])
+            else:
+                p.process_blocks_device(xs[i * B:(i + 1) * B], y)
+            ys.append(y)
+        torch.cuda.synchronize()
+        out = torch.cat(ys, 0).permute(1, 2, 0, 3).reshape(S, 2, T).cpu().numpy()
+        return out, [p.pitch_state(s) for s in range(min(S, U))], p.debug_stamps()[59:62]
+
+    ref, st_ref, _ = run(None)
+    got, st_got, timeouts = run(True)
+    assert list(timeouts) == [0, 0, 0]
+    assert np.isfinite(got).all()
+    bad = np.nonzero(got != ref)
+    assert bad[0].size == 0, f"{bad[0].size} samples differ, first at stream {bad[0][0]}, sample {bad[2][0]}"
+    for a, b_ in zip(st_ref, st_got):
+        for k in ("period", "pitch", "beta", "anMarks", "stMarks", "gateOpen"):
+            assert np.array_equal(a[k], b_[k]), k
+    if iir == "exact":
+        want = _oracle(base, N, dict(vocBool=0))
+        assert np.array_equal(got[:U], want)
+    assert np.abs(got).max() > 0.05

@@ -56,6 +56,7 @@ struct vp_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     double *acc2 = nullptr;
     int overlap = 0, acc2Live = 0;
+    int timeParallel = 0;                       // vp_set_time_parallel: multi-block pitch launches behind the analysis front end (vp_k_pitch_front)
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
@@ -124,6 +125,15 @@ static bool pitch_common(const vp_handle *h)
     return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512 && h->g.eLen >= h->g.F + 4 * h->g.tauMax + 1;
 }
 
+// geometry and modes for which the analysis front end of multi-block launches (vp_k_pitch_front) can stand in for the serial kernel's
+// YIN phase: the eight-lag cross-correlation's layout (vp_pitch.inc xc8_ok), every LPC lag on one wavefront, 512-thread roles
+static bool pitch_front_ok(const vp_handle *h)
+{
+    const VpGeom &g = h->g;
+    return (g.F & 63) == 0 && (g.C & 1) == 0 && g.tauMax <= 512 && g.eLen >= g.F + 4 * g.tauMax + 1 && g.orderPitch < 64 &&
+           vp_pitch_front_lds_bytes(g) <= h->ldsMax && h->timeParallel;
+}
+
 // THE selection of the pitch-kernel build for a launch (used by the launch site and by vp_pitch_kernel_name alike)
 typedef void (*vp_dsp_kernel)(VpGeom, VpCall, VpDev, const float *, float *);
 struct PitchPlan { vp_dsp_kernel fn; const char *name; size_t lds; };
@@ -133,8 +143,10 @@ static PitchPlan pitch_plan(const vp_handle *h, bool fast, bool fft, int nBlocks
     const bool lite = pitch_lite(h, fast, fft), com = pitch_common(h);
     const size_t lds = h->pitchLds;
     if (fft) return fast ? VP_PLAN(vp_k_pitch_fast_fft, lds + vp_pitch_fft_lds_bytes(h->g)) : VP_PLAN(vp_k_pitch_fft, lds + vp_pitch_fft_lds_bytes(h->g));   // never `lite` (pitch_lite)
-    if (nBlocks > 1)                                      // never with `lite` (process_blocks_device)
+    if (nBlocks > 1) {                                    // (`lite` multi-block launches exist for the FAST recursion only: process_blocks_device)
+        if (lite) return com ? VP_PLAN(vp_k_pitch_lite_fast_multi_c, lds) : VP_PLAN(vp_k_pitch_lite_fast_multi, lds);
         return fast ? (com ? VP_PLAN(vp_k_pitch_fast_multi_c, lds) : VP_PLAN(vp_k_pitch_fast_multi, lds)) : VP_PLAN(vp_k_pitch_multi, lds);
+    }
     if (lite) return fast ? (com ? VP_PLAN(vp_k_pitch_lite_fast_c, lds) : VP_PLAN(vp_k_pitch_lite_fast, lds)) : VP_PLAN(vp_k_pitch_lite, lds);
     if (com) return fast ? VP_PLAN(vp_k_pitch_fast_c, lds) : VP_PLAN(vp_k_pitch_c, lds);
     return fast ? VP_PLAN(vp_k_pitch_fast, lds) : VP_PLAN(vp_k_pitch, lds);
@@ -198,6 +210,13 @@ extern "C" int vp_set_overlap(vp_handle *h, int on)
     return VP_OK;
 }
 extern "C" int vp_get_overlap(const vp_handle *h) { return h ? h->overlap : VP_ERR_INVALID_ARG; }
+extern "C" int vp_set_time_parallel(vp_handle *h, int on)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    h->timeParallel = on ? 1 : 0;
+    return VP_OK;
+}
+extern "C" int vp_get_time_parallel(const vp_handle *h) { return h ? h->timeParallel : VP_ERR_INVALID_ARG; }
 
 extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
 {
@@ -569,7 +588,8 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
                              (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
-                             (const void *)vp_k_pitch_lite_fast_c,
+                             (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
+                             (const void *)vp_k_pitch_front, (const void *)vp_k_pitch_front_fast,
                              (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -592,6 +612,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.yFrame, (size_t)S * F));
     RC(dev_alloc(h, &d.EeArr, (size_t)S * 20));
     RC(dev_alloc(h, &d.hImp, (size_t)S * 128));
+    RC(dev_alloc(h, &d.front, (size_t)S * VP_FRONT_MAX));
     RC(dev_alloc(h, &d.ub, (size_t)5));
     RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S));        // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks
     RC(dev_upload(h, &d.vocWin, vocWin));
@@ -894,6 +915,32 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
                 ProfScope ps(h, st, 2);
                 PitchPlan plan = pitch_plan(h, cp.iirFast != 0, cp.yinFft != 0, nBlocks);
+                if (nBlocks > 1 && !cp.yinFft && pitch_front_ok(h)) {
+                    // yin() and the LPC of every frame that starts inside the launch, one workgroup per (stream, frame),
+                    // ahead of the serial kernel.  The frame starts follow from the counters (PitchProcess.cpp:166-196).
+                    VpFront fr;
+                    memset(&fr, 0, sizeof fr);
+                    int pS_ = co.pStart, nCh = co.nChunk;
+                    bool fits = true;
+                    for (int b = 0; b < nBlocks && fits; b++) {
+                        for (; pS_ < g.N; pS_ += g.C) {
+                            if (nCh == 0 || nCh == g.cpf - 1) {
+                                if (fr.nFr == VP_FRONT_MAX) { fits = false; break; }
+                                fr.start[fr.nFr++] = b * g.N + pS_;
+                                nCh = 0;
+                            }
+                            nCh += 1;
+                        }
+                        pS_ -= g.N;
+                    }
+                    if (fits && fr.nFr > 0) {
+                        VpCall cf = cp;
+                        cf.ldsBytes = (int)vp_pitch_front_lds_bytes(g);
+                        hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_front_fast : vp_k_pitch_front, dim3(co.n, fr.nFr), dim3(512), vp_pitch_front_lds_bytes(g), st,
+                                           g, cf, d, fr, d_in);
+                        cp.front = 1;
+                    }
+                }
                 // one workgroup per CU anyway (S <= 256 or a frame beyond half a CU's LDS): the block's accumulator slice rides in LDS
                 if (nBlocks == 1 && !cp.yinFft && !pitch_lite(h, cp.iirFast != 0, false) && plan.lds + vp_pitch_acc_lds_bytes(g) + 16 <= h->ldsMax) {
                     cp.ldsAcc = 1;
@@ -1043,7 +1090,9 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     if (rc) { h->poisoned = true; return rc; }
     const bool fast = h->iirMode == VP_IIR_FAST, fft = h->yinMode == VP_YIN_FFT && h->g.fftLog > 0;
     const bool pitchOnly = h->cohorts.size() == 1 && h->cohorts[0].pitchOn && !h->cohorts[0].vocOn;
-    if (pitchOnly && n_blocks > 1 && !fft && !pitch_lite(h, fast, fft))      // one launch: state stays on chip between the blocks
+    // one launch of the serial kernel for all the blocks (state stays on chip between them), behind the time-parallel analysis
+    // front end where the geometry allows it; above 256 streams the register-light builds exist for the FAST recursion only
+    if (pitchOnly && n_blocks > 1 && !fft && (!pitch_lite(h, fast, fft) || fast))
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
     const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
     if (!mono && n_blocks > 1) {                               // vocoder-only plan on the batched pipeline: groups of blocks per launch

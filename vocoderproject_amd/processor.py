@@ -102,6 +102,8 @@ def load_library():
     if hasattr(L, "vp_set_overlap"):
         L.vp_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.vp_get_overlap.argtypes = [C.c_void_p]
+    L.vp_set_time_parallel.argtypes = [C.c_void_p, C.c_int]
+    L.vp_get_time_parallel.argtypes = [C.c_void_p]
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
     L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vp_set_yin_mode.argtypes = [vp, C.c_int]
@@ -205,6 +207,10 @@ class BatchVocoderProcessor:
     def set_overlap(self, on):
         """FAST mode, both processes, batched vocoder: pitch corrector beside the vocoder pipeline (default) or behind it."""
         self._chk(self.L.vp_set_overlap(self.h, int(bool(on))))
+
+    def set_time_parallel(self, on):
+        """Multi-block pitch-only calls behind the time-parallel analysis front end (vp_k_pitch_front; off by default, see include/vp_amd.h)."""
+        self._chk(self.L.vp_set_time_parallel(self.h, int(bool(on))))
 
     def set_yin_mode(self, mode):
         """"direct" (default, reference summation order) or "fft" (VP_YIN_FFT accelerator)."""
