@@ -474,7 +474,7 @@ def main():
         value_long = {"value": frames_per_step_gpu * kl * n_gpus / dtl, "steps": kl, "ms_per_step": dtl / kl * 1e3}
 
     # The other BASELINE configs at their per-GPU share, so that one driver run (at every N) carries a figure for each of them.
-    def leg(what, mode_, S_, fs_, N_, hop_, prepare, params, steps_, with_exchange=False):
+    def leg(what, mode_, S_, fs_, N_, hop_, prepare, params, steps_, with_exchange=False, blocks=0):
         q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **params)
         if prepare:
             q.prepareExplicit(fs_, N_, S_, *prepare)
@@ -494,6 +494,14 @@ def main():
         out_["hbm_frac_algorithmic"] = out_["alg_bytes_per_step_per_gpu"] / (dtl_ / steps_) / 1e9 / HBM_PEAK_GBS
         if do_exchange and with_exchange:
             out_["exchange"] = exchange_region(q, S_, N_, fs_, hop_, False, max(8, steps_ // 2))
+        if blocks > 1:                              # the same blocks handed over `blocks` at a time (vp_process_blocks_device)
+            xb = xl.repeat(blocks // 4 + 1, 1, 1, 1)[:blocks].contiguous()
+            yb = torch.empty((blocks, S_, 2, N_), dtype=torch.float32, device=dev)
+            kb = max(3, steps_ // blocks)
+            dtb = region(lambda i: q.process_blocks_device(xb, yb, stream.cuda_stream), kb, 2)
+            (dtb,) = max_over_ranks(dtb)
+            out_[f"value_{blocks}_blocks_per_call"] = (S_ * N_ // hop_) * blocks * kb * n_gpus / dtb
+            del xb, yb
         del q, xl, yl
         return out_
 
@@ -506,7 +514,7 @@ def main():
                     "window_1024_256": leg("configs[2]: 256 streams, vocoder, lpcVoice 24, the metric's 1024/256 window", "voc", 256, 44100.0, 1024, 256,
                                            (1024, 768, 1024, 256), {"lpcVoice": 24}, k4)}
         if not (mode == "both" and S == 1024):
-            cfg3 = leg("configs[3] per GPU: 1024 streams, pitch corrector + vocoder", "both", 1024, 44100.0, 1024, 256, None, {}, k4, with_exchange=True)
+            cfg3 = leg("configs[3] per GPU: 1024 streams, pitch corrector + vocoder", "both", 1024, 44100.0, 1024, 256, None, {}, k4, with_exchange=True, blocks=8)
         cfg4 = leg("configs[4] per GPU: 512 streams @48 kHz, 2048-pt frames hop 512, orders 48/48/30, pitch corrector + vocoder", "both", 512,
                    48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(6, args.steps // 16))
 

@@ -137,7 +137,12 @@ int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_o
  * vocoder alone (LPC orders <= 48, any batch size) groups of up to 16 blocks run as ONE launch of the lane-per-window
  * pipeline -- the window grid carries across blocks, so B blocks are B times the windows, i.e. B times the lanes; every block
  * keeps its own ring ingest, silence gate and output slab (256 streams, 8 blocks per call: 2.1x the single-call throughput,
- * 3x in exact mode); the combined plan is issued block by block.  Parameters are read once, at entry. */
+ * 3x in exact mode).  With BOTH enabled, in VP_IIR_FAST, groups of up to 16 blocks run as one launch of the serial pitch kernel
+ * followed by one launch of the pipeline (the pitch kernel ingests the blocks and adds its chunks into a linear accumulator of the
+ * call, the pipeline works from a snapshot of the rings and folds that accumulator in when it emits): every decision is the
+ * block-by-block path's, the audio equals it to rounding level (the additions into the output accumulator happen chunks-first
+ * instead of windows-first; 256 streams, 8 blocks per call: 1.4x the single-call throughput).  In VP_IIR_EXACT the combined plan
+ * is issued block by block.  Parameters are read once, at entry. */
 int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream);
 /* The same from HOST memory: in float [n_blocks][n_streams][3][N], out float [n_blocks][n_streams][2][N]; one upload,
  * the blocks, one download, synchronises before returning (staging buffers grow on demand; VP_ERR_OOM). */

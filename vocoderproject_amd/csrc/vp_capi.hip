@@ -48,6 +48,9 @@ struct vp_handle {
     VpV2 v2mb;                                  // the same scratch sized for several blocks per launch (allocated on first use)
     int v2mbWin = 0;                            // windows per stream it holds
     std::vector<void *> mbAllocs;
+    // combined multi-block plan (process_both_blocks): ring snapshots, per-block gates, the pitch corrector's linear accumulator
+    float *snapV = nullptr, *snapS = nullptr; int *gateB = nullptr; double *pLin = nullptr;
+    std::vector<void *> bothAllocs;
     // vp_set_overlap(h, 1), VP_IIR_FAST, both processes on, batched vocoder: the pitch kernel runs beside the vocoder pipeline on
     // auxStream and adds into its own accumulator (acc2), which emit merges.  acc2Live: blocks for which acc2 may still hold
     // something.  Off by default: measured 404 vs 408 us per block at 1024 streams, 880 vs 820 us at the configs[4] geometry --
@@ -287,6 +290,8 @@ static void free_all(vp_handle *h)
     h->stageIn = h->stageOut = nullptr; h->dMapAll = nullptr; h->cohorts.clear(); h->acc2 = nullptr;
     for (void *p : h->mbAllocs) (void)hipFree(p);
     h->mbAllocs.clear(); h->v2mbWin = 0; memset(&h->v2mb, 0, sizeof h->v2mb); memset(&h->v2, 0, sizeof h->v2);
+    for (void *p : h->bothAllocs) (void)hipFree(p);
+    h->bothAllocs.clear(); h->snapV = h->snapS = nullptr; h->gateB = nullptr; h->pLin = nullptr;
     if (h->stageInB) (void)hipFree(h->stageInB);
     if (h->stageOutB) (void)hipFree(h->stageOutB);
     h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
@@ -1080,6 +1085,124 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     return VP_OK;
 }
 
+static int ensure_both(vp_handle *h)
+{
+    if (h->pLin) return VP_OK;
+    const VpGeom &g = h->g;
+    auto get = [&](auto **p, size_t count) -> bool {
+        void *q = nullptr;
+        if (hipMalloc(&q, count * sizeof(**p)) != hipSuccess) return false;
+        h->bothAllocs.push_back(q);
+        (void)hipMemset(q, 0, count * sizeof(**p));
+        *p = (std::remove_reference_t<decltype(**p)> *)q;
+        return true;
+    };
+    const bool ok = get(&h->snapV, (size_t)g.S * g.inSize) && get(&h->snapS, (size_t)g.S * 2 * g.inSize) &&
+                    get(&h->gateB, (size_t)V2_MB_MAX * g.S * 2) && get(&h->pLin, (size_t)g.S * ((size_t)V2_MB_MAX * g.N + g.outSize));
+    if (!ok) {
+        for (void *p : h->bothAllocs) (void)hipFree(p);
+        h->bothAllocs.clear(); h->snapV = h->snapS = nullptr; h->gateB = nullptr; h->pLin = nullptr;
+        h->lastError = "out of device memory for the combined multi-block plan";
+        return VP_ERR_OOM;
+    }
+    return VP_OK;
+}
+
+// vp_process_blocks_device, BOTH processes on, VP_IIR_FAST, batched vocoder pipeline: up to V2_MB_MAX consecutive blocks as one launch
+// of the serial pitch kernel (state on chip across the blocks) followed by one launch of the vocoder pipeline over all the blocks'
+// windows.  The pitch kernel goes first: it ingests the blocks (both gates per block -> gateB) and adds its chunks into a linear
+// accumulator of the call (pLin); the vocoder kernels read the rings as they stood BEFORE the call from a snapshot, and their
+// overlap-add/emit kernel folds pLin in.  What is given up against the block-by-block plan is the order of the additions into the
+// output accumulator (chunks before windows instead of windows before chunks, PluginProcessor.cpp:214-221): rounding-level, which is
+// why the plan exists in the tolerance mode only.  Returns VP_OK + *done = false when the plan does not apply.
+static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, int nb, hipStream_t st, bool *done)
+{
+    *done = false;
+    const VpGeom &g = h->g;
+    if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX || h->iirMode != VP_IIR_FAST) return VP_OK;
+    auto &co = h->cohorts[0];
+    if (!co.vocOn || !co.pitchOn || !h->v2.xT || h->vocPath == VP_VOC_WORKGROUP) return VP_OK;
+    if (co.oVmax > V2_ORDER_MAX || co.oSmax > VP_ORDER_MAX_SYNTH || co.oVmax < 2 || co.oSmax < 2) return VP_OK;
+    if ((size_t)g.outSize * sizeof(double) > (size_t)VP_V2_MB_LDS_MAX) return VP_OK;
+    if (h->yinMode == VP_YIN_FFT && g.fftLog > 0) return VP_OK;
+    VpV2MB mb;
+    memset(&mb, 0, sizeof mb);
+    mb.nBlocks = nb; mb.preIngested = 1;
+    int vs = co.vStart, NWs = 0;
+    for (int b = 0; b < nb; b++) {                                           // VocoderProcess.cpp:173-183 block after block
+        const int nWin = (vs < g.N) ? (g.N - vs + g.h - 1) / g.h : 0;
+        mb.vStart[b] = vs; mb.nWin[b] = nWin; mb.first[b] = NWs;
+        NWs += nWin;
+        vs = vs + nWin * g.h - g.N;
+    }
+    if (NWs < 1 || mb.nWin[0] < 1) return VP_OK;
+    for (int b = 1; b < nb; b++)
+        if (mb.nWin[b] > 0 && b * g.N + mb.vStart[b] != mb.vStart[0] + mb.first[b] * g.h) return VP_OK;
+    if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
+    int rc = ensure_v2mb(h, NWs);
+    if (rc) return rc;
+    if ((rc = ensure_both(h)) != VP_OK) return rc;
+    h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
+    struct Poison { vp_handle *h; bool armed; ~Poison() { if (armed) h->poisoned = true; } } guard{h, true};
+    HIPCHK(h, hipMemcpyAsync(h->snapV, h->d.voiceRing, (size_t)g.S * g.inSize * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->snapS, h->d.synthRing, (size_t)g.S * 2 * g.inSize * sizeof(float), hipMemcpyDeviceToDevice, st));
+    VpCall c;
+    memset(&c, 0, sizeof c);
+    c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
+    c.iirFast = 1; c.nBlocks = nb; c.inMono = 0; c.vocOn = 1; c.pitchOn = 1;
+    c.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
+    VpDev d = h->d;
+    d.streamMap = co.dMap;
+    d.gateB = h->gateB;
+    {   // the pitch corrector: every block of the call, chunks into the linear accumulator
+        VpGeom gp = g;
+        gp.outSize = V2_MB_MAX * g.N + g.outSize;
+        VpCall cp = c;
+        cp.outCounter = 0;
+        cp.pStart = co.pStart; cp.nChunk0 = co.nChunk;
+        cp.nSteps = (co.pStart < g.N) ? (g.N - co.pStart + g.C - 1) / g.C : 0;
+        cp.fuseIngest = 1; cp.fuseEmit = 0; cp.pitchLin = 1;
+        VpDev dp = d;
+        dp.outAcc = h->pLin; dp.outAcc2 = nullptr;
+        const PitchPlan plan = pitch_plan(h, true, false, nb);
+        cp.ldsBytes = (int)plan.lds;
+        ProfScope ps(h, st, 2);
+        hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, gp, cp, dp, d_in, d_out);
+    }
+    {   // the vocoder: all the windows of the call, from the snapshot and the call's input; its last kernel emits
+        VpCall cv = c;
+        cv.vStart = mb.vStart[0]; cv.nWin = NWs; cv.fuseIngest = 1; cv.fuseEmit = 1;
+        VpDev dv = d;
+        dv.voiceRing = h->snapV; dv.synthRing = h->snapS;
+        dv.pLin = h->pLin;
+        dv.outAcc2 = h->acc2Live > 0 ? h->acc2 : nullptr;
+        VpV2 v = h->v2mb;
+        v.nStreams = co.n; v.oVmax = co.oVmax; v.oSmax = co.oSmax;
+        ProfScope ps(h, st, 1);
+        vp_v2_launch_blocks(g, cv, dv, v, mb, d_in, d_out, st);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(h, e, "kernel launch");
+    co.vStart = vs;
+    for (int b = 0; b < nb; b++) {                                           // PitchProcess.cpp:169-195, once per block
+        const int nSteps = (co.pStart < g.N) ? (g.N - co.pStart + g.C - 1) / g.C : 0;
+        int nChunk = co.nChunk;
+        for (int i = 0; i < nSteps; i++) nChunk = (nChunk % g.cpf == g.cpf - 1) ? 1 % g.cpf : nChunk + 1;
+        co.nChunk = nChunk;
+        co.pStart = co.pStart + nSteps * g.C - g.N;
+    }
+    h->synthNonZero = g.inSize;
+    h->acc2Live = std::max(0, h->acc2Live - nb);
+    for (int b = 0; b < nb; b++) {                                           // MyBuffer.cpp:129-132
+        h->outCounter = (h->outCounter + g.N) % g.outSize;
+        h->inCounter = (h->inCounter + g.N) % g.inSize;
+        h->currCounter = (h->currCounter + g.N) % g.inSize;
+    }
+    guard.armed = false;
+    *done = true;
+    return VP_OK;
+}
+
 static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream, bool mono)
 {
     if (!h || !d_in || !d_out || n_blocks < 1) return VP_ERR_INVALID_ARG;
@@ -1101,6 +1224,8 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
             const int nb = std::min(n_blocks - b, V2_MB_MAX);
             bool done = false;
             rc = process_voc_blocks(h, d_in + b * nIn, d_out + b * nOut, nb, (hipStream_t)hip_stream, &done);
+            if (rc) return rc;
+            if (!done) rc = process_both_blocks(h, d_in + b * nIn, d_out + b * nOut, nb, (hipStream_t)hip_stream, &done);
             if (rc) return rc;
             if (!done) break;
             b += nb;

@@ -54,6 +54,7 @@ struct VpCall {
                                  // already (nothing to write, nothing to sum for its gate)
     int nBlocks;                 // pitch kernel with both fusions: consecutive blocks handled by this launch (>= 1);
                                  // the counters above describe the first, the kernel advances them itself
+    int pitchLin;                // pitch kernel, combined multi-block plan: gates to VpDev::gateB, no emit (see VpDev::pLin)
     int front;                   // pitch kernel, multi-block launch: the frames' yin() and LPC come from vp_k_pitch_front's records
     int ldsAcc;                  // pitch kernel: the launch carries vp_pitch_acc_lds_bytes() more dynamic LDS, in which the block's
                                  // slice of the output accumulator lives while the chunks add to it (one read and one write
@@ -117,6 +118,12 @@ struct VpDev {
                              // VP_IIR_FAST mode the pitch corrector can run BESIDE the vocoder pipeline (another HIP stream) and
                              // then adds into this one; emit merges (and clears) both
     VpFrontRec *front;       // [S][VP_FRONT_MAX] records of the analysis front end (multi-block launches)
+    // combined multi-block plan (pitch corrector AND vocoder, several blocks per call, VP_IIR_FAST): the pitch kernel runs first, ingests
+    // the blocks, leaves each block's two gates in gateB and adds its chunks into the LINEAR accumulator pLin (sample t of the call at
+    // pLin[s][t]) instead of the accumulator ring; the vocoder pipeline then works from a snapshot of the rings as they stood before
+    // the call and its overlap-add/emit kernel takes pLin in
+    int *gateB;              // [V2_MB_MAX][S][2]
+    double *pLin;            // [S][pLinLen]
     const int *streamMap;    // launch of a cohort (streams whose pitchBool/vocBool histories differ from the others'):
                              // workgroup b serves stream streamMap[b]; nullptr (the normal case): stream b
 };

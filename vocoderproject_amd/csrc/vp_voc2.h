@@ -31,7 +31,9 @@ struct VpV2 {
 // multi-block launches (vp_process_blocks_device, vocoder-only plan): per block of the launch
 #define V2_MB_MAX 16
 #define VP_V2_MB_LDS_MAX (160 * 1024 - 1024)      // dynamic-LDS ceiling vp_v2_init() sets on vp_k_v2_mb_ola_emit (it holds outSize doubles)
-struct VpV2MB { int nBlocks, vStart[V2_MB_MAX], nWin[V2_MB_MAX], first[V2_MB_MAX]; };
+// preIngested: the blocks are in the ring already and their gates in VpDev::gateB (combined plan: the pitch kernel ran first); the
+// samples then come from the ring SNAPSHOT the caller put into VpDev::voiceRing / synthRing
+struct VpV2MB { int nBlocks, vStart[V2_MB_MAX], nWin[V2_MB_MAX], first[V2_MB_MAX], preIngested; };
 
 int vp_v2_init();
 void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const VpV2MB &mb, const float *d_in, float *d_out,

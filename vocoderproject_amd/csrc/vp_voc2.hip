@@ -652,6 +652,10 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ingest_stage(VpGeom g, VpCall 
     }
     __syncthreads();
     // b. the blocks into the ring one after the other, each with its own gate (MyBuffer.cpp:74-105, VocoderProcess.cpp:199-204)
+    if (mb.preIngested) {
+        if (tid < mb.nBlocks) gl[tid] = d.gateB[((size_t)tid * g.S + s) * 2 + 0] && d.gateB[((size_t)tid * g.S + s) * 2 + 1];
+        __syncthreads();
+    } else
     for (int bl = 0; bl < mb.nBlocks; bl++) {
         ingest_gate_block(g, c, d, in + (size_t)bl * g.S * 3 * g.N, bl * g.N);
         if (tid == 0) gl[bl] = d.gate[s * 2 + 0] && d.gate[s * 2 + 1];
@@ -687,6 +691,7 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
     double *acc = d.outAcc + (size_t)s * g.outSize;
     double *acc2 = d.outAcc2 ? d.outAcc2 + (size_t)s * g.outSize : nullptr;
     const double *o = v.out + (size_t)wBase * W;
+    double *pl = d.pLin ? d.pLin + (size_t)s * ((size_t)V2_MB_MAX * g.N + g.outSize) : nullptr;
     for (int t = tid; t < BN + g.outSize; t += blockDim.x) {
         double val = 0.0;
         if (t < g.outSize) {
@@ -701,6 +706,7 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
                 if (i >= 0 && i < W && v.meta[wBase + k].x) val += gainVoc * o[(size_t)k * W + i] * d.vocWin[i];
             }
         }
+        if (pl) { val += pl[t]; pl[t] = 0.0; }                               // the pitch corrector's chunks of this call (and the slot cleared for the next)
         if (t < BN) {
             const int bl = t / g.N, i = t - bl * g.N;
             auto smp = [&](int ch) -> double { return (double)((t < g.latency) ? v.dry[((size_t)b * 3 + ch) * g.latency + t] : v2_mb_src(g, c, d, in, s, ch, t)); };

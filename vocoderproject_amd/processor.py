@@ -298,7 +298,8 @@ class BatchVocoderProcessor:
 
     def process_blocks_device(self, d_in, d_out, stream=None):
         """B consecutive blocks at once: torch float32 tensors [B][S][3][N] -> [B][S][2][N]; same results as B calls of
-        process_device (pitch corrector alone: ONE launch, state stays on chip between the blocks)."""
+        process_device (pitch corrector alone: ONE launch, state stays on chip between the blocks; vocoder alone, or both in the
+        fast IIR mode: groups of up to 16 blocks per launch of the pipeline -- see include/vp_amd.h)."""
         assert d_in.is_cuda and d_out.is_cuda and d_in.is_contiguous() and d_out.is_contiguous()
         B = d_in.shape[0]
         assert tuple(d_in.shape) == (B, self.n_streams, 3, self.N) and tuple(d_out.shape) == (B, self.n_streams, 2, self.N)
