@@ -613,7 +613,8 @@ def test_per_stream_parameters():
 @pytest.mark.parametrize("iir", ["exact", "fast"])
 def test_multi_block_launch_equals_block_by_block(iir):
     """vp_process_blocks_device: B blocks in one launch give exactly what B single-block calls give (and, in exact
-    mode, what the oracle gives), gate crossings and unvoiced stretches included; other plans fall back to single calls."""
+    mode, what the oracle gives), gate crossings and unvoiced stretches included; other plans fall back to single calls
+    (both processes in the fast IIR mode: the combined plan, equal to rounding level with identical decisions)."""
     import torch
     from vocoderproject_amd import BatchVocoderProcessor
     S, N, B = 6, 1024, 24
@@ -637,7 +638,12 @@ def test_multi_block_launch_equals_block_by_block(iir):
         ref, st_ref, ub_ref = run([1] * B, **params)
         for split in ([B], [5, 1, 7, 11], [2] * 12):
             got, st, ub = run(split, **params)
-            _assert_equal(got, ref, f"{params} split {split}")
+            if iir == "fast" and not params:
+                # both processes, tolerance mode: the combined multi-block plan adds chunks before windows and
+                # takes the vocoder pipeline's recursion -- rounding-level differences, every decision identical (below)
+                assert np.abs(got - ref).max() < 2e-6, (split, np.abs(got - ref).max())
+            else:
+                _assert_equal(got, ref, f"{params} split {split}")
             assert ub == ub_ref
             for s_ in range(S):
                 for k in st_ref[s_]:
