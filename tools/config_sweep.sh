@@ -35,3 +35,10 @@ run --cfg5 --mode pitch --streams 512
 run --cfg5 --mode voc --streams 512
 run --cfg5 --mode voc --streams 512 --voc-path batched
 run --cfg5 --mode both --streams 256
+# round 3: several blocks per call with both processes on (the combined plan), and the pitch corrector's multi-block builds
+run --mode both --streams 256 --three-channel
+run --mode both --streams 256 --three-channel --blocks-per-step 8
+run --mode both --streams 1024 --three-channel --blocks-per-step 8
+run --mode pitch --streams 256 --blocks-per-step 8
+run --mode pitch --streams 1024 --blocks-per-step 8
+run --mode voc --streams 256 --three-channel --blocks-per-step 8

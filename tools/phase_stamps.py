@@ -14,10 +14,14 @@ os.environ.setdefault("VP_AMD_LIB", os.path.join(ROOT, "vocoderproject_amd", "li
 
 PHASES = {15: "pitch: prologue (ingest, gate, state/frame/window loads)", 0: "pitch: loop top", 1: "pitch: YIN diff + autocorr", 2: "pitch: cum/normalise/pick", 3: "pitch: an marks",
           4: "pitch: st marks", 5: "pitch: levinson", 6: "pitch: FIR start", 7: "pitch: psola", 8: "pitch: IIR",
-          9: "pitch: fill output", 12: "pitch:   (cum sum)", 13: "pitch:   (normalise)", 14: "pitch:   (psola qtab+grain table)", 10: "pitch: FIR cont", 11: "pitch: state out",
-          24: "pitch:   (block IIR carry-in, all chunks)", 25: "pitch:   (block IIR 64-term dot, all chunks)",
+          9: "pitch: fill output", 12: "pitch:   (cum sum)", 13: "pitch:   (normalise / block IIR: wait for the zero-state responses)", 14: "pitch:   (psola qtab+grain table)", 10: "pitch: FIR cont", 11: "pitch: state out",
+          24: "pitch:   (block IIR: carry-in / history matrix, all chunks)", 25: "pitch:   (block IIR: 64-term dot / walk over the blocks, all chunks)",
           28: "pitch:   (an marks: roll + first mark)", 29: "pitch:   (an marks: walk to the right)",
           26: "pitch:   (last wave: LPC autocorrelation)", 27: "pitch:   (last wave: Levinson-Durbin)",
+          30: "pitch:   (last wave: impulse response)",
+          32: "pitch:   (marks phase, wave 0 busy)", 33: "pitch:   (marks phase, wave 1 busy)", 34: "pitch:   (marks phase, wave 2 busy)",
+          35: "pitch:   (marks phase, wave 3 busy)", 36: "pitch:   (marks phase, wave 4 busy)", 37: "pitch:   (marks phase, wave 5 busy)",
+          38: "pitch:   (marks phase, wave 6 busy)", 39: "pitch:   (marks phase, wave 7 busy)",
           40: "pitch:   (YIN phase, wave 0 busy)", 41: "pitch:   (YIN phase, wave 1 busy)", 42: "pitch:   (YIN phase, wave 2 busy)",
           43: "pitch:   (YIN phase, wave 3 busy)", 44: "pitch:   (YIN phase, wave 4 busy)", 45: "pitch:   (YIN phase, wave 5 busy)",
           46: "pitch:   (YIN phase, wave 6 busy)", 47: "pitch:   (YIN phase, wave 7 busy)",
@@ -25,6 +29,9 @@ PHASES = {15: "pitch: prologue (ingest, gate, state/frame/window loads)", 0: "pi
           54: "pitch:   (scan phase, wave 6 busy)", 55: "pitch:   (scan phase, wave 7 busy)",
           16: "voc: load", 17: "voc: autocorr", 18: "voc: levinson", 19: "voc: FIR", 20: "voc: energies",
           21: "voc: gains", 22: "voc: IIR", 23: "voc: scale+OLA"}
+
+
+PITCH_ONLY = {16 + w: f"pitch:   (IIR phase, wave {w} busy)" for w in range(8)}     # (the vocoder's ids, free in a pitch-only run)
 
 
 def main():
@@ -61,16 +68,20 @@ def main():
     st = p.debug_stamps()
     # ids < 24 are consecutive stretches of thread 0's timeline (they add up to the kernels' duration); ids >= 24 are
     # timers of OTHER wavefronts or nested stretches, concurrent with the former
-    tot = sum(t for i, t in enumerate(st) if i < 24)
+    names = dict(PHASES)
+    if a.mode == "pitch":
+        names.update(PITCH_ONLY)
+    timeline = lambda i: i < 16 or (i < 24 and a.mode != "pitch")
+    tot = sum(t for i, t in enumerate(st) if timeline(i))
     print(f"mode={a.mode} S={S} N={N} iir={a.iir}: per-step microseconds of workgroup 0, thread 0's timeline (sum {tot / a.steps:.1f})")
     for i, t in enumerate(st):
-        if t and i < 24:
-            print(f"  {str(PHASES.get(i, i)):44s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
-    if any(st[24:]):
+        if t and timeline(i):
+            print(f"  {str(names.get(i, i)):44s} {t / a.steps:9.1f} us  {100 * t / tot:5.1f} %")
+    if any(st[16:]):
         print("concurrent / nested timers:")
         for i, t in enumerate(st):
-            if t and 24 <= i < 62:                       # 62/63 are frame counters of VP_YIN_XCORR, not timers
-                print(f"  {str(PHASES.get(i, i)):44s} {t / a.steps:9.1f} us")
+            if t and not timeline(i) and i < 62:         # 62/63 are frame counters of VP_YIN_XCORR, not timers
+                print(f"  {str(names.get(i, i)):44s} {t / a.steps:9.1f} us")
 
 if __name__ == "__main__":
     main()

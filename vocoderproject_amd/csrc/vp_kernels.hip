@@ -80,6 +80,28 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_LPC_FAST
 #define VP_LPC_FAST 1           /* VP_IIR_FAST: LPC autocorrelation with the sum over n split across the lanes (autocorr_rows_fast); 0 = the ordered sums */
 #endif
+#ifndef VP_ACR_AHEAD
+#define VP_ACR_AHEAD 1          /* ... its operands requested a trip ahead (two register sets; not in the 128-register builds) */
+#endif
+#ifndef VP_HC_WAVE
+#define VP_HC_WAVE 5
+#endif
+#ifndef VP_FIR_TWO
+#define VP_FIR_TWO 1            /* the next chunk's residual beside the recursion: on two wavefronts (full workgroups) */
+#endif
+#ifndef VP_HC_TWO
+#define VP_HC_TWO 1             /* FAST block recursion of orders 17..48: zero-state responses on a second wavefront beside the history matrix */
+#endif
+#ifndef VP_ACR_FUSE
+#define VP_ACR_FUSE 1           /* ... orders above 32: three groups of sixteen lags per pass, operands shared between the groups (autocorr_rows_fast3) */
+#endif
+#ifndef VP_LEV_TREE
+#define VP_LEV_TREE 1           /* ... and its Levinson-Durbin (orders 16..48) with rotation-tree sums (levinson_row48<true>); 0 = the ordered chains */
+#endif
+#ifndef VP_LPC_LATE
+#define VP_LPC_LATE 2           /* ... orders >= 16: lag groups on the two wavefronts the YIN phase leaves idle; 2 = the last one then runs Levinson-Durbin in
+                                   that phase (it waits for the other's groups), 1 = the recursion opens the marks phase, 0 = one wavefront does it all */
+#endif
 #ifndef VP_AC_ROWS
 #define VP_AC_ROWS 1            /* exact modes, orders below 32: LPC autocorrelation with lane-parallel products and DPP-ordered sums (autocorr_rows_exact8) */
 #endif
