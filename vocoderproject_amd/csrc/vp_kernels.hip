@@ -83,6 +83,12 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_ACR_AHEAD
 #define VP_ACR_AHEAD 1          /* ... its operands requested a trip ahead (two register sets; not in the 128-register builds) */
 #endif
+#ifndef VP_FIR4_SELECT
+#define VP_FIR4_SELECT 1        /* fir4: the filter's first outputs as the four-chain select form (0 = the scalar loop) */
+#endif
+#ifndef VP_LPC_HAND15
+#define VP_LPC_HAND15 0         /* FAST, orders below 16: 1 = LPC autocorrelation on wave 6, Levinson-Durbin on wave 7 (measured neutral: 16.2 M either way) */
+#endif
 #ifndef VP_HC_WAVE
 #define VP_HC_WAVE 5
 #endif

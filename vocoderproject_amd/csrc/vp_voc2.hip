@@ -358,6 +358,9 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
 // The voice's and the side chain's coefficient / residual kernels are ONE launch each (blockIdx.y resp. blockIdx.z selects;
 // the side chain's orders are much smaller -- its own template parameter -- and its wavefronts fill in beside the voice's
 // instead of queueing behind them: 34 -> 24 us and 22 -> 18 us at 1024 streams).
+// (round 3, measured and dropped: the autocorrelation's sums split into 2 or 4 stretches of n, a wavefront each, in VP_IIR_FAST mode
+// -- "more wavefronts for few, long windows": configs[4] geometry 312.7 -> 299 (2 parts) / 322 us (4 parts), 1024 streams 162.5 -> 170 /
+// 189 us: every extra wavefront refills its window-function copy and its register ring, and the kernel is not short of wavefronts)
 // (round 3, measured and dropped: the two sums of an order step with four partial accumulators each in VP_IIR_FAST mode -- no gain,
 // 18.4 us either way at order 40: the fully unrolled recursion is ~8000 instructions executed once per wavefront, bound by
 // instruction fetch, not by the sums' dependent chains)
