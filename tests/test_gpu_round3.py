@@ -22,14 +22,17 @@ def _oracle(x, N, params):
     return np.stack(outs)
 
 
-@pytest.mark.parametrize("S,N,B,iir,yin", [(6, 1024, 8, "exact", "direct"), (6, 1024, 8, "exact", "xcorr"), (5, 1024, 3, "fast", "xcorr"),
-                                           (4, 256, 7, "exact", "xcorr"), (300, 1024, 8, "fast", "xcorr"), (7, 2048, 2, "exact", "xcorr")])
-def test_time_parallel_front_end_equals_block_by_block(S, N, B, iir, yin):
+@pytest.mark.parametrize("S,N,B,iir,yin,lpc", [(6, 1024, 8, "exact", "direct", 15), (6, 1024, 8, "exact", "xcorr", 15), (5, 1024, 3, "fast", "xcorr", 15),
+                                               (4, 256, 7, "exact", "xcorr", 15), (300, 1024, 8, "fast", "xcorr", 15), (7, 2048, 2, "exact", "xcorr", 15),
+                                               (5, 1024, 3, "fast", "xcorr", 48), (4, 1024, 4, "fast", "xcorr", 40), (4, 1024, 3, "fast", "direct", 33),
+                                               (4, 1024, 3, "exact", "xcorr", 24), (3, 1024, 2, "exact", "xcorr", 48)])
+def test_time_parallel_front_end_equals_block_by_block(S, N, B, iir, yin, lpc):
     """with vp_set_time_parallel on, a multi-block pitch-only call computes yin() and the LPC of every frame that starts
     inside it in vp_k_pitch_front (a workgroup per stream and frame) and the serial kernel consumes the records.  Same routines,
     same modes: the output must be the block-by-block path's bit for bit (and, in the exact modes, the oracle's), over gate
     crossings, cold starts, frames that straddle calls, blocks shorter than a frame, and the register-light builds above 256
-    streams."""
+    streams.  LPC orders above 15: the serial kernel takes the fused three-group autocorrelation on one wavefront and the recursion on
+    another (fast mode: levinson_fast64), the front end the group-by-group form on one -- same sums, same order, same bits."""
     import torch
     from vocoderproject_amd import BatchVocoderProcessor
     calls = 3
@@ -42,7 +45,7 @@ def test_time_parallel_front_end_equals_block_by_block(S, N, B, iir, yin):
     x = np.ascontiguousarray(base[np.arange(S) % U])
 
     def run(tp):
-        p = BatchVocoderProcessor(vocBool=0)
+        p = BatchVocoderProcessor(vocBool=0, lpcPitch=lpc)
         p.prepareToPlay(FS, N, S)
         p.set_iir_mode(iir)
         p.set_yin_mode(yin)
@@ -71,8 +74,12 @@ def test_time_parallel_front_end_equals_block_by_block(S, N, B, iir, yin):
         for k in ("period", "pitch", "beta", "anMarks", "stMarks", "gateOpen"):
             assert np.array_equal(a[k], b_[k]), k
     if iir == "exact":
-        want = _oracle(base, N, dict(vocBool=0))
+        want = _oracle(base, N, dict(vocBool=0, lpcPitch=lpc))
         assert np.array_equal(got[:U], want)
+    else:
+        want = _oracle(base, N, dict(vocBool=0, lpcPitch=lpc))
+        rms = np.sqrt(np.mean((got[:U].astype(np.float64) - want) ** 2))
+        assert rms < 1e-4, rms                                                                     # BASELINE.json north_star tolerance
     assert np.abs(got).max() > 0.05
 
 
