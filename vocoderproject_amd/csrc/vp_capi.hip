@@ -553,6 +553,10 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     const size_t ldsMax = std::min<size_t>((size_t)prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536, 160 * 1024) - 256;
     // stage the voice window of as many consecutive chunk steps as fit comfortably (the whole block if possible)
     g.xsSteps = 1;
+    // batches that can use the two-workgroups-per-CU builds: no LDS copy of the frame's Hann window (read from the global table,
+    // same values), which lets the block's later chunk steps be staged inside the 80 KB -- and with them the overlap of the next
+    // chunk's residual / PSOLA with the current chunk's recursion
+    g.htabGlobal = (g.S > 256 && !getenv("VP_NO_HTAB_GLOBAL")) ? 1 : 0;
     {
         const int stepsMax = (N + g.C - 1) / g.C;
         // batches that can use the two-workgroups-per-CU build keep the frame within half a CU's LDS

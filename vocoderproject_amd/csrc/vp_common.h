@@ -30,6 +30,8 @@ struct VpGeom {
     int bufferIdxMax;    // latency + N (PitchProcess.cpp:138)
     int fftLog;          // log2 of the FFT size of the VP_YIN_FFT accelerator (>= F + tauMax points), 0 = unavailable
     int xsSteps;         // chunk steps whose voice window is staged in LDS at once (pitch kernel)
+    int htabGlobal;      // pitch kernel: the frame's Hann(2T+1) window is read from the global table instead of an LDS copy (batches of
+                         // more than 256 streams: the 7 KB buy the staging of the block's later chunk steps within half a CU's LDS)
     double fs, delta, yinTol;
     double gateThrSum;   // smallest sum(x^2) over the ring for which 20log10(rms) >= -60 dB
     double levEps;       // pow(10,-9)  LPC.cpp:110
@@ -144,7 +146,7 @@ VP_HD static inline int vp_cum_len(int tauMax) { return tauMax + 1 > 448 ? tauMa
 // bytes of dynamic LDS vp_k_pitch needs for a geometry
 VP_HD static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
 {
-    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (2 * (size_t)g.tauMax + 2);
+    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (g.htabGlobal ? 0 : 2 * (size_t)g.tauMax + 2);
     return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
 }
 // dynamic LDS of the analysis front end (vp_k_pitch_front): YIN window, prefix sums + quarter sums, yinTemp, running sum, r, a, scratch, state
