@@ -118,7 +118,8 @@ extern "C" const char *vp_last_error(const vp_handle *h) { return h ? h->lastErr
 // register-resident exact-IIR instantiation)
 static bool pitch_lite(const vp_handle *h, bool iirFast, bool yinFft)
 {
-    return h->g.S > 256 && !yinFft && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024;
+    // (htabGlobal: the register-light builds are compiled for the global Hann table only; prepare sets it for exactly these batches)
+    return h->g.S > 256 && !yinFft && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024 && h->g.htabGlobal;
 }
 
 // geometry and order for which the common-case builds (vp_k_pitch*_c) are valid
@@ -556,7 +557,14 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     // batches that can use the two-workgroups-per-CU builds: no LDS copy of the frame's Hann window (read from the global table,
     // same values), which lets the block's later chunk steps be staged inside the 80 KB -- and with them the overlap of the next
     // chunk's residual / PSOLA with the current chunk's recursion
-    g.htabGlobal = (g.S > 256 && !getenv("VP_NO_HTAB_GLOBAL")) ? 1 : 0;
+    // (exactly the batches the register-light builds serve -- pitch_lite(): more than 256 streams and a frame that fits half a CU
+    // with one step staged; they are compiled for the global table only)
+    g.htabGlobal = 0;
+    if (g.S > 256) {
+        VpGeom t = g;
+        t.xsSteps = 1;
+        if (vp_pitch_lds_bytes(t) <= (size_t)80 * 1024) g.htabGlobal = 1;
+    }
     {
         const int stepsMax = (N + g.C - 1) / g.C;
         // batches that can use the two-workgroups-per-CU build keep the frame within half a CU's LDS
