@@ -641,7 +641,10 @@ def test_multi_block_launch_equals_block_by_block(iir):
             if iir == "fast" and not params:
                 # both processes, tolerance mode: the combined multi-block plan adds chunks before windows and
                 # takes the vocoder pipeline's recursion -- rounding-level differences, every decision identical (below)
-                assert np.abs(got - ref).max() < 2e-6, (split, np.abs(got - ref).max())
+                # (the two plans run different tolerance-mode vocoders at this batch size -- lane-per-window pipeline vs workgroup
+                # kernel with split-sum autocorrelations: an ill-conditioned order-40 analysis moves by 1e-5 between them)
+                dlt = got.astype(np.float64) - ref
+                assert np.sqrt(np.mean(dlt ** 2)) < 1e-5 and np.abs(dlt).max() < 1e-4, (split, np.sqrt(np.mean(dlt ** 2)), np.abs(dlt).max())
             else:
                 _assert_equal(got, ref, f"{params} split {split}")
             assert ub == ub_ref

@@ -83,6 +83,9 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_ACR_AHEAD
 #define VP_ACR_AHEAD 1          /* ... its operands requested a trip ahead (two register sets; not in the 128-register builds) */
 #endif
+#ifndef VP_VOC_AC_FAST
+#define VP_VOC_AC_FAST 1        /* workgroup vocoder, VP_IIR_FAST: autocorrelations with split sums on the windowed samples (0 = the ordered sums) */
+#endif
 #ifndef VP_FIR4_SELECT
 #define VP_FIR4_SELECT 1        /* fir4: the filter's first outputs as the four-chain select form (0 = the scalar loop) */
 #endif
