@@ -86,6 +86,9 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_VOC_AC_FAST
 #define VP_VOC_AC_FAST 1        /* workgroup vocoder, VP_IIR_FAST: autocorrelations with split sums on the windowed samples (0 = the ordered sums) */
 #endif
+#ifndef VP_VOC_E_FAST
+#define VP_VOC_E_FAST 1         /* ... and the residual energies as lane-parallel partial sums (0 = the ordered sums) */
+#endif
 #ifndef VP_FIR4_SELECT
 #define VP_FIR4_SELECT 1        /* fir4: the filter's first outputs as the four-chain select form (0 = the scalar loop) */
 #endif
