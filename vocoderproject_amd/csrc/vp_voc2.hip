@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, 
 // (LPC.cpp:58-96: outer n, inner m).  Lane = window; the wave takes L consecutive lags [m0, m0+L) of the voice
 // (blockIdx.y < gV) or of the side chain.  The lane's L+7 samples x[n+m0 ..] slide through registers (eight steps per
 // trip, names rotate statically), the window function comes through scalar registers (uniform index).
-template <int L>
+// FS (VP_IIR_FAST, round 3): the lane's ring holds the WINDOWED samples x[n+m] w[n+m] (one multiply per new sample) and a term is
+// ONE fused multiply-add tmp[n] * (x w)[n+m] instead of two multiplies and an add -- 2.2x fewer vector instructions per trip.  The
+// reference's association ((x[n] w[n]) x[n+m]) w[n+m] and its two roundings per term are given up: tolerance-mode arithmetic.
+template <int L, bool FS = false>
 __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
     static_assert(L == 4 || L == 8, "lag groups of 4 or 8");
@@ -165,17 +168,19 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
 #endif
         double R[16];
 #pragma unroll
-        for (int t = 0; t < L; t++) R[t] = (double)x[m0 + t];
+        for (int t = 0; t < L; t++) R[t] = FS ? (double)x[m0 + t] * V2_AC_WIN(m0 + t) : (double)x[m0 + t];
         float4 au0, au1, ax0, ax1, bu0, bu1, bx0, bx1, cu0, cu1, cx0, cx1, du0, du1, dx0, dx1;
 #define V2_AC_LOAD(U0, U1, X0, X1, N) { U0 = *(const float4 *)&x.base[(size_t)((N) >> 2) * 256]; U1 = *(const float4 *)&x.base[(size_t)(((N) >> 2) + 1) * 256]; \
         X0 = *(const float4 *)&x.base[(size_t)(((N) + m0 + L) >> 2) * 256]; X1 = *(const float4 *)&x.base[(size_t)((((N) + m0 + L) >> 2) + 1) * 256]; }
 #define V2_AC_TRIP(PH, U0, U1, X0, X1, N) { \
         const float fx_[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w}, fu_[8] = {U0.x, U0.y, U0.z, U0.w, U1.x, U1.y, U1.z, U1.w}; \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) R[(L + t + PH) & 15] = (double)fx_[t]; \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) R[(L + t + PH) & 15] = FS ? (double)fx_[t] * V2_AC_WIN(min((N) + m0 + L + t, W - 1)) : (double)fx_[t]; \
         double u[8]; \
         _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * V2_AC_WIN((N) + t);          /* tmp, LPC.cpp:61 */ \
         _Pragma("unroll") for (int t = 0; t < 8; t++) { \
-            _Pragma("unroll") for (int j = 0; j < L; j++) { double p = u[t] * R[(t + j + PH) & 15]; p = p * V2_AC_WIN((N) + t + m0 + j); sum[j] += p; } } }
+            _Pragma("unroll") for (int j = 0; j < L; j++) { \
+                if (FS) sum[j] = __builtin_fma(u[t], R[(t + j + PH) & 15], sum[j]); \
+                else { double p = u[t] * R[(t + j + PH) & 15]; p = p * V2_AC_WIN((N) + t + m0 + j); sum[j] += p; } } } }
         // (requests run TWO trips ahead -- four named buffer sets, four trips per loop iteration: with one or two wavefronts
         // per SIMD a trip of 0.2-0.4 us does not cover a memory round trip)
         V2_AC_LOAD(au0, au1, ax0, ax1, 0)
@@ -205,9 +210,12 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
 #pragma unroll
         for (int j = 0; j < L; j++) {
             if (n < W - m0 - j) {
+                if (FS) sum[j] = __builtin_fma(u, (double)x[n + m0 + j] * wl[n + m0 + j], sum[j]);
+                else {
                 double p = u * (double)x[n + m0 + j];
                 p = p * wl[n + m0 + j];
                 sum[j] += p;
+                }
             }
         }
     }
@@ -773,18 +781,25 @@ int vp_v2_init()
     return 0;
 }
 
+static bool v2_ac_fs() { static const bool on = !getenv("VP_V2_NO_AC_FS"); return on; }   // (diagnostic switch for A/B runs)
+
 // autocorrelation ... all-pole output for the NW = nStreams x c.nWin windows the stage kernel has laid out
 static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, hipStream_t st)
 {
     const int NW = v.nStreams * c.nWin, nGroups = (NW + 63) / 64;
     if (NW <= 0) return;
     // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
-    if (nGroups * ((v.oVmax + 8) / 8 + (v.oSmax + 8) / 8) >= 1024) {
+    static const int forceL = getenv("VP_V2_AC_L") ? atoi(getenv("VP_V2_AC_L")) : 0;     // (diagnostic)
+    // (the fused-multiply-add form is lighter on the vector ALUs and bound by its loads, which eight lags per wavefront halve: it takes
+    // the switch a little earlier -- 1024 streams at the default geometry are 896 such wavefronts: 158 -> 155 us)
+    if (forceL ? forceL == 8 : nGroups * ((v.oVmax + 8) / 8 + (v.oSmax + 8) / 8) >= ((c.iirFast && v2_ac_fs()) ? 832 : 1024)) {
         const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
-        V2_LAUNCH(vp_k_v2_autocorr<8>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
+        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<8, true>), dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
+        else V2_LAUNCH(vp_k_v2_autocorr<8>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
     } else {
         const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
-        V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
+        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<4, true>), dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
+        else V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
     }
     v2_launch_lpc_fir(v.oVmax, v.oSmax, nGroups, g.W, st, g, c, d, v);
     if (c.iirFast) {
