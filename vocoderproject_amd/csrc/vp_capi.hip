@@ -632,6 +632,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.front, (size_t)S * VP_FRONT_MAX));
     RC(dev_alloc(h, &d.ub, (size_t)5));
     RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S));        // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks
+    vocWin.resize((size_t)W + 16, 0.0);                                      // (zero padding: vp_k_v2_autocorr fetches whole 8-entry stretches)
     RC(dev_upload(h, &d.vocWin, vocWin));
     RC(dev_upload(h, &d.pitchStWin, pitchSt));
     RC(dev_upload(h, &d.hannTab, hannTab));

@@ -172,37 +172,54 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         float4 au0, au1, ax0, ax1, bu0, bu1, bx0, bx1, cu0, cu1, cx0, cx1, du0, du1, dx0, dx1;
 #define V2_AC_LOAD(U0, U1, X0, X1, N) { U0 = *(const float4 *)&x.base[(size_t)((N) >> 2) * 256]; U1 = *(const float4 *)&x.base[(size_t)(((N) >> 2) + 1) * 256]; \
         X0 = *(const float4 *)&x.base[(size_t)(((N) + m0 + L) >> 2) * 256]; X1 = *(const float4 *)&x.base[(size_t)((((N) + m0 + L) >> 2) + 1) * 256]; }
-#define V2_AC_TRIP(PH, U0, U1, X0, X1, N) { \
+        // The window function's values of a trip -- w[N .. N+7] for tmp and, in the FS form, w[N+m0+L .. +7] for the ring's new entries
+        // (d.vocWin is zero-padded by 16 entries) -- as TWO wide scalar loads requested one trip ahead (WU/WX: two named sets).
+        // Left to itself the compiler fetched them piecemeal where they were used: three or four scalar-cache round trips in a row
+        // per trip (scalar loads return out of order, so each batch ended in a wait for all of them) -- more than the trip's
+        // arithmetic.
+        // (WX: w[N+m0 ..]: the FS form uses entries L .. L+7, the reference form entries t + j = 0 .. L+6)
+        constexpr int NWX = FS ? 8 : L + 8;
+        double wuA[8], wxA[NWX], wuB[8], wxB[NWX];
+#define V2_AC_WLOAD(WU, WX, N) { const double *__restrict__ pu_ = &V2_AC_WIN(N), *__restrict__ px_ = &V2_AC_WIN((N) + m0 + (FS ? L : 0)); \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) WU[t] = pu_[t]; \
+        _Pragma("unroll") for (int t = 0; t < NWX; t++) WX[t] = px_[t]; }
+#define V2_AC_TRIP(PH, U0, U1, X0, X1, N, WU, WX) { \
         const float fx_[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w}, fu_[8] = {U0.x, U0.y, U0.z, U0.w, U1.x, U1.y, U1.z, U1.w}; \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) R[(L + t + PH) & 15] = FS ? (double)fx_[t] * V2_AC_WIN(min((N) + m0 + L + t, W - 1)) : (double)fx_[t]; \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) R[(L + t + PH) & 15] = FS ? (double)fx_[t] * WX[t] : (double)fx_[t]; \
         double u[8]; \
-        _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * V2_AC_WIN((N) + t);          /* tmp, LPC.cpp:61 */ \
+        _Pragma("unroll") for (int t = 0; t < 8; t++) u[t] = (double)fu_[t] * WU[t];                        /* tmp, LPC.cpp:61 */ \
         _Pragma("unroll") for (int t = 0; t < 8; t++) { \
             _Pragma("unroll") for (int j = 0; j < L; j++) { \
                 if (FS) sum[j] = __builtin_fma(u[t], R[(t + j + PH) & 15], sum[j]); \
-                else { double p = u[t] * R[(t + j + PH) & 15]; p = p * V2_AC_WIN((N) + t + m0 + j); sum[j] += p; } } } }
+                else { double p = u[t] * R[(t + j + PH) & 15]; p = p * WX[t + j]; sum[j] += p; } } } }
         // (requests run TWO trips ahead -- four named buffer sets, four trips per loop iteration: with one or two wavefronts
         // per SIMD a trip of 0.2-0.4 us does not cover a memory round trip)
         V2_AC_LOAD(au0, au1, ax0, ax1, 0)
         V2_AC_LOAD(bu0, bu1, bx0, bx1, 8)
+        V2_AC_WLOAD(wuA, wxA, 0)
         for (int n = 0; n < nMain; n += 32) {
             V2_AC_LOAD(cu0, cu1, cx0, cx1, n + 16)
-            V2_AC_TRIP(0, au0, au1, ax0, ax1, n)
+            V2_AC_WLOAD(wuB, wxB, n + 8)
+            V2_AC_TRIP(0, au0, au1, ax0, ax1, n, wuA, wxA)
             if (n + 8 < nMain) {
                 V2_AC_LOAD(du0, du1, dx0, dx1, n + 24)
-                V2_AC_TRIP(8, bu0, bu1, bx0, bx1, n + 8)
+                V2_AC_WLOAD(wuA, wxA, n + 16)
+                V2_AC_TRIP(8, bu0, bu1, bx0, bx1, n + 8, wuB, wxB)
             }
             if (n + 16 < nMain) {
                 V2_AC_LOAD(au0, au1, ax0, ax1, n + 32)
-                V2_AC_TRIP(0, cu0, cu1, cx0, cx1, n + 16)
+                V2_AC_WLOAD(wuB, wxB, n + 24)
+                V2_AC_TRIP(0, cu0, cu1, cx0, cx1, n + 16, wuA, wxA)
             }
             if (n + 24 < nMain) {
                 V2_AC_LOAD(bu0, bu1, bx0, bx1, n + 40)
-                V2_AC_TRIP(8, du0, du1, dx0, dx1, n + 24)
+                V2_AC_WLOAD(wuA, wxA, n + 32)
+                V2_AC_TRIP(8, du0, du1, dx0, dx1, n + 24, wuB, wxB)
             }
         }
 #undef V2_AC_LOAD
 #undef V2_AC_TRIP
+#undef V2_AC_WLOAD
 #undef V2_AC_WIN
     }
     for (int n = nMain; n < W - m0; n++) {                                  // the last steps: lags drop out one by one
