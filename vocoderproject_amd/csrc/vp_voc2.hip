@@ -306,7 +306,9 @@ __device__ __forceinline__ void v2_levinson_body(const VpGeom &g, const VpCall &
 // isS = 0: voice -> eV, 1: side chain -> eS (a launch of its own: its orders are much smaller).
 // Also leaves the slice's own sum of e^2 (in order) in EEp: VP_IIR_FAST takes the window energies as the sum of those (the
 // reference's single left-to-right sum -- vp_k_v2_energy -- stays the exact mode's), and then eVoice is not stored at all.
-template <int P>
+// FS (VP_IIR_FAST, round 3): a tap is ONE fused multiply-add instead of a product and an addition (half the vector instructions of
+// the kernel; one rounding per tap instead of two: tolerance-mode arithmetic)
+template <int P, bool FS = false>
 __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
     static_assert(P % 4 == 0 && P >= 4, "P multiple of 4");
@@ -346,7 +348,7 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
             double acc = a[0] * xn[t]; \
             _Pragma("unroll") for (int k = 1; k <= P; k++) { \
                 const double xv_ = (k <= t) ? xn[t - k < 0 ? 0 : t - k] : h[k - 1 - t < 0 ? 0 : k - 1 - t]; \
-                acc += xv_ * a[k]; } \
+                if (FS) acc = __builtin_fma(xv_, a[k], acc); else acc += xv_ * a[k]; } \
             en[t] = acc; } \
         _Pragma("unroll") for (int t = P - 1; t >= 4; t--) h[t] = h[t - 4]; \
         h[3] = xn[0]; h[2] = xn[1]; h[1] = xn[2]; h[0] = xn[3]; \
@@ -395,11 +397,11 @@ __global__ __launch_bounds__(64) void vp_k_v2_levinson2(VpGeom g, VpCall c, VpDe
     if (blockIdx.y == 0) v2_levinson_body<PV>(g, c, d, v, 0);
     else v2_levinson_body<PS>(g, c, d, v, 1);
 }
-template <int PV, int PS>
+template <int PV, int PS, bool FS = false>
 __global__ __launch_bounds__(64) void vp_k_v2_fir2(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
-    if (blockIdx.z == 0) v2_fir_body<PV>(g, c, d, v, 0);
-    else v2_fir_body<PS>(g, c, d, v, 1);
+    if (blockIdx.z == 0) v2_fir_body<PV, FS>(g, c, d, v, 0);
+    else v2_fir_body<PS, FS>(g, c, d, v, 1);
 }
 
 // VP_IIR_FAST: window energies as the in-order sum of the slices' sums.  (A kernel of its own, 5 us: summed inside the
@@ -765,12 +767,14 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
 #define V2_LAUNCH(K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, st, __VA_ARGS__)
 #define V2_LAUNCH_ON(SX, K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, SX, __VA_ARGS__)
 
+static bool v2_fir_fs() { static const bool on = !getenv("VP_V2_NO_FIR_FS"); return on; }   // (diagnostic switch for A/B runs)
 // <PV, PS>: orders rounded up to the instantiated sizes (voice 8..48 in steps of 8; side chain 8, 16, 24, 32)
 template <int PV> static void v2_launch_lpc_fir_v(int ps, const dim3 &gl, const dim3 &gf, hipStream_t st, const VpGeom &g, const VpCall &c,
                                                    const VpDev &d, const VpV2 &v)
 {
 #define V2_PAIR(PS) { V2_LAUNCH((vp_k_v2_levinson2<PV, PS>), gl, dim3(64), 0, g, c, d, v); \
-                      V2_LAUNCH((vp_k_v2_fir2<PV, PS>), gf, dim3(64), (size_t)((PV > PS ? PV : PS) + V2_FIR_SLICE + 8) * 8, g, c, d, v); }
+                      if (c.iirFast && v2_fir_fs()) V2_LAUNCH((vp_k_v2_fir2<PV, PS, true>), gf, dim3(64), (size_t)((PV > PS ? PV : PS) + V2_FIR_SLICE + 8) * 8, g, c, d, v); \
+                      else V2_LAUNCH((vp_k_v2_fir2<PV, PS>), gf, dim3(64), (size_t)((PV > PS ? PV : PS) + V2_FIR_SLICE + 8) * 8, g, c, d, v); }
     if (ps <= 8) V2_PAIR(8) else if (ps <= 16) V2_PAIR(16) else if (ps <= 24) V2_PAIR(24) else V2_PAIR(32)
 #undef V2_PAIR
 }
