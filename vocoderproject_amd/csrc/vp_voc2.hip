@@ -251,7 +251,9 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
 // waiting for the round trips inside the two ordered sums: 47 us against 18 us at order 40).  The coefficient update is done
 // on the pair (i, p - i) at once -- each new value is old[i] - k * old[p - i], the same operands and operation as the
 // reference's pass over a copy.  A lane whose own order is smaller steps out of the remaining order steps (EXEC mask).
-template <int P>
+// FS (VP_IIR_FAST, round 3): sums and updates as fused multiply-adds -- half the instructions of a recursion that is executed once
+// per wavefront and bound by instruction fetch (four partial accumulators per sum, tried before, did not change the count)
+template <int P, bool FS = false>
 __device__ __forceinline__ void v2_levinson_body(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int isS)
 {
     const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
@@ -278,15 +280,21 @@ __device__ __forceinline__ void v2_levinson_body(const VpGeom &g, const VpCall &
             double rho_a = 0.0, r_a = 0.0;
 #pragma unroll
             for (int i = 1; i < p; i++) {                                   // :120-128
+                if (FS) { rho_a = __builtin_fma(r[p - i], a[i], rho_a); r_a = __builtin_fma(r[i], a[i], r_a); }
+                else {
                 rho_a += r[p - i] * a[i];
                 r_a += r[i] * a[i];
+                }
             }
             const double k = (r[p] - rho_a) / (r0 - r_a);
 #pragma unroll
             for (int i = 1; 2 * i <= p; i++) {                              // a[i] = aPrev[i] - k aPrev[p-i], both ends of the pair
                 const double ai = a[i], aj = a[p - i];
+                if (FS) { a[i] = __builtin_fma(-k, aj, ai); if (2 * i != p) a[p - i] = __builtin_fma(-k, ai, aj); }
+                else {
                 a[i] = ai - k * aj;
                 if (2 * i != p) a[p - i] = aj - k * ai;
+                }
             }
             a[p] = k;
         }
@@ -391,11 +399,11 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
 // (round 3, measured and dropped: the two sums of an order step with four partial accumulators each in VP_IIR_FAST mode -- no gain,
 // 18.4 us either way at order 40: the fully unrolled recursion is ~8000 instructions executed once per wavefront, bound by
 // instruction fetch, not by the sums' dependent chains)
-template <int PV, int PS>
+template <int PV, int PS, bool FS = false>
 __global__ __launch_bounds__(64) void vp_k_v2_levinson2(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
-    if (blockIdx.y == 0) v2_levinson_body<PV>(g, c, d, v, 0);
-    else v2_levinson_body<PS>(g, c, d, v, 1);
+    if (blockIdx.y == 0) v2_levinson_body<PV, FS>(g, c, d, v, 0);
+    else v2_levinson_body<PS, FS>(g, c, d, v, 1);
 }
 template <int PV, int PS, bool FS = false>
 __global__ __launch_bounds__(64) void vp_k_v2_fir2(VpGeom g, VpCall c, VpDev d, VpV2 v)
@@ -767,12 +775,14 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
 #define V2_LAUNCH(K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, st, __VA_ARGS__)
 #define V2_LAUNCH_ON(SX, K, GRID, BLOCK, LDS, ...) hipLaunchKernelGGL(K, GRID, BLOCK, LDS, SX, __VA_ARGS__)
 
+static bool v2_lev_fs() { static const bool on = !getenv("VP_V2_NO_LEV_FS"); return on; }   // (diagnostic switch for A/B runs)
 static bool v2_fir_fs() { static const bool on = !getenv("VP_V2_NO_FIR_FS"); return on; }   // (diagnostic switch for A/B runs)
 // <PV, PS>: orders rounded up to the instantiated sizes (voice 8..48 in steps of 8; side chain 8, 16, 24, 32)
 template <int PV> static void v2_launch_lpc_fir_v(int ps, const dim3 &gl, const dim3 &gf, hipStream_t st, const VpGeom &g, const VpCall &c,
                                                    const VpDev &d, const VpV2 &v)
 {
-#define V2_PAIR(PS) { V2_LAUNCH((vp_k_v2_levinson2<PV, PS>), gl, dim3(64), 0, g, c, d, v); \
+#define V2_PAIR(PS) { if (c.iirFast && v2_lev_fs()) V2_LAUNCH((vp_k_v2_levinson2<PV, PS, true>), gl, dim3(64), 0, g, c, d, v); \
+                      else V2_LAUNCH((vp_k_v2_levinson2<PV, PS>), gl, dim3(64), 0, g, c, d, v); \
                       if (c.iirFast && v2_fir_fs()) V2_LAUNCH((vp_k_v2_fir2<PV, PS, true>), gf, dim3(64), (size_t)((PV > PS ? PV : PS) + V2_FIR_SLICE + 8) * 8, g, c, d, v); \
                       else V2_LAUNCH((vp_k_v2_fir2<PV, PS>), gf, dim3(64), (size_t)((PV > PS ? PV : PS) + V2_FIR_SLICE + 8) * 8, g, c, d, v); }
     if (ps <= 8) V2_PAIR(8) else if (ps <= 16) V2_PAIR(16) else if (ps <= 24) V2_PAIR(24) else V2_PAIR(32)
