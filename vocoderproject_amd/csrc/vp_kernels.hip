@@ -89,6 +89,9 @@ __device__ unsigned long long vp_last_w[16];
 #ifndef VP_VOC_FIR4
 #define VP_VOC_FIR4 1           /* workgroup vocoder: residual FIRs as four consecutive outputs per lane (fir4); 0 = eight outputs 64 apart (fir_window8) */
 #endif
+#ifndef VP_VOC_FIR_FS
+#define VP_VOC_FIR_FS 1         /* ... and the residual FIRs (fir_window8) */
+#endif
 #ifndef VP_VOC_LEV_FS
 #define VP_VOC_LEV_FS 1         /* ... and the lane-per-window Levinson-Durbin with fused multiply-adds (0 = the reference's two roundings per term) */
 #endif
