@@ -497,7 +497,7 @@ def main():
         if blocks > 1:                              # the same blocks handed over `blocks` at a time (vp_process_blocks_device)
             xb = xl.repeat(blocks // 4 + 1, 1, 1, 1)[:blocks].contiguous()
             yb = torch.empty((blocks, S_, 2, N_), dtype=torch.float32, device=dev)
-            kb = max(3, steps_ // blocks)
+            kb = max(6, steps_ // blocks)
             dtb = region(lambda i: q.process_blocks_device(xb, yb, stream.cuda_stream), kb, 2)
             (dtb,) = max_over_ranks(dtb)
             out_[f"value_{blocks}_blocks_per_call"] = (S_ * N_ // hop_) * blocks * kb * n_gpus / dtb
@@ -506,7 +506,7 @@ def main():
         return out_
 
     cfg2 = cfg3 = cfg4 = None
-    k4 = max(8, args.steps // 8)
+    k4 = max(40, args.steps // 4)                      # (a leg is milliseconds: long enough for a stable figure whatever --steps is)
     if not args.single_mode and not args.cfg5 and BPS == 1:
         if not (mode == "voc" and args.lpc_voice == 24):
             cfg2 = {"window_512_128": leg("configs[2]: 256 streams, vocoder, lpcVoice 24, the reference's 512/128 window", "voc", 256, 44100.0, 1024, 256,
@@ -516,7 +516,7 @@ def main():
         if not (mode == "both" and S == 1024):
             cfg3 = leg("configs[3] per GPU: 1024 streams, pitch corrector + vocoder", "both", 1024, 44100.0, 1024, 256, None, {}, k4, with_exchange=True, blocks=8)
         cfg4 = leg("configs[4] per GPU: 512 streams @48 kHz, 2048-pt frames hop 512, orders 48/48/30, pitch corrector + vocoder", "both", 512,
-                   48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(6, args.steps // 16))
+                   48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(32, args.steps // 6))
 
     total_frames = frames_per_step_gpu * args.steps * n_gpus
     value = total_frames / dt
