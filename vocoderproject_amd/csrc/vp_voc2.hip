@@ -577,23 +577,24 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
         V2_IF_STEPS \
         _Pragma("unroll") for (int k = 0; k < NI; k++) if (live[k]) out[k][(I) + m] = yo_[k]; }
     const int W16 = W & ~15;
-    double xa[NI], xb[NI];
+    // (round 3) the trip's one load is requested THREE trips ahead (four named registers): a trip is 16 samples x ~44 issue cycles,
+    // 0.3 us -- with one wavefront per SIMD (few, long windows) or two, one trip of lead did not cover a round trip to memory
+    // (the residuals of a block are tens of megabytes: they do not come from L2), and the recursion sat out the difference
+    double xa[NI], xb[NI], xc[NI], xd[NI];
 #pragma unroll
-    for (int k = 0; k < NI; k++) { xa[k] = (W16 > 0) ? es[k][m] : 0.0; xb[k] = 0.0; }
-    for (int i = 0; i < W16; i += 32) {
-        if (i + 16 < W16) {
-#pragma unroll
-            for (int k = 0; k < NI; k++) xb[k] = es[k][i + 16 + m];
-        }
-        V2_IF_TRIP(xa, i)
-        if (i + 16 < W16) {
-            if (i + 32 < W16) {
-#pragma unroll
-                for (int k = 0; k < NI; k++) xa[k] = es[k][i + 32 + m];
-            }
-            V2_IF_TRIP(xb, i + 16)
-        }
+    for (int k = 0; k < NI; k++) {
+        xa[k] = (W16 > 0) ? es[k][m] : 0.0; xb[k] = (W16 > 16) ? es[k][16 + m] : 0.0;
+        xc[k] = (W16 > 32) ? es[k][32 + m] : 0.0; xd[k] = (W16 > 48) ? es[k][48 + m] : 0.0;
     }
+#define V2_IF_NEXT(X, I) if ((I) < W16) { _Pragma("unroll") for (int k = 0; k < NI; k++) X[k] = es[k][(I) + m]; }
+    for (int i = 0; i < W16; i += 64) {
+        V2_IF_TRIP(xa, i)
+        V2_IF_NEXT(xa, i + 64)
+        if (i + 16 < W16) { V2_IF_TRIP(xb, i + 16) V2_IF_NEXT(xb, i + 80) }
+        if (i + 32 < W16) { V2_IF_TRIP(xc, i + 32) V2_IF_NEXT(xc, i + 96) }
+        if (i + 48 < W16) { V2_IF_TRIP(xd, i + 48) V2_IF_NEXT(xd, i + 112) }
+    }
+#undef V2_IF_NEXT
     if (W16 < W) {                                                          // the ragged end: same steps, masked loads and stores
         double xr[NI], yo_[NI], gx_[NI][16];
 #pragma unroll
