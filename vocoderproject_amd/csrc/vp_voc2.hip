@@ -564,8 +564,8 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
         double s0 = st[k][0]; \
         asm volatile("s_nop 1" : "+v"(s0), "+v"(yy));                       /* VALU write -> DPP read */ \
         VP_FMAC_BCAST(yy, s0, one, 0);                                      /* + s_1, held by lane 0 of the row */ \
-        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s0), 0x101, 0xf, 0xf, false);    /* row_shl:1: lane m <- lane m + 1, */ \
-        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s0), 0x101, 0xf, 0xf, false);    /* 0 into the row's last lane      */ \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s0), 0x101, 0xf, 0xf, true);     /* row_shl:1: lane m <- lane m + 1, */ \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s0), 0x101, 0xf, 0xf, true);     /* 0 into the row's last lane (bound_ctrl: no pre-zeroed destination, two moves fewer per sample) */ \
         const double in_ = __hiloint2double(hi_, lo_); \
         _Pragma("unroll") for (int j = 0; j + 1 < T; j++) st[k][j] = __builtin_fma(na[k][j], yy, st[k][j + 1]); \
         st[k][T - 1] = __builtin_fma(na[k][T - 1], yy, in_); \
