@@ -22,6 +22,10 @@ Besides the contract fields the line carries
                   name and by a hash of the kernel sources, null when either differs)
   cpu_baseline -- the CPU oracle (the build's restatement of the reference, kind "port") timed on
                   this host's cores on a bounded sample of the same workload (rank 0, one GPU only)
+  parity       -- the accuracy half of the metric ("...; RMS err vs CPU ref"): after the timed regions, sampled streams of a FRESH
+                  processor of the same configuration (same builds, modes, batch) against the CPU oracle on the same input:
+                  rms_err, max_abs_err, rms_rel, decision_mismatch_frames (tracker states that differ), streams, blocks.  One per
+                  leg: the headline (`parity`, `parity_exact_mode`, `parity_pm12_semitone_shift`) and configs2/3/4 (`.parity`)
   rccl         -- (N > 1, or --exchange) what torch.distributed backend "nccl" (= RCCL) saw: world size, the
                   all-reduced sum of ranks
   exchange     -- SURVEY 8(e)'s root fan-out/fan-in: rank 0 holds the whole batch, per step scatter_streams ->
@@ -31,7 +35,8 @@ Besides the contract fields the line carries
   configs3     -- the same hot path at BASELINE configs[3]'s per-GPU share (1024 streams, pitch + vocoder)
   configs4     -- BASELINE configs[4]'s per-GPU share: 48 kHz, 2048-pt frames hop 512, orders 48/48/30, 512 streams, both
                   processes (its frames are 512-sample hops)
-  value_long   -- the headline workload again over >= 2000 steps (a 20-step driver run times 1.7 ms; this is the stable figure)
+  value_long   -- the headline workload again for about --long-seconds (6 s: a 20-step driver run times 1.3 ms; this is the stable
+                  figure, and the stretch in which an outside observer's rocm-smi samples see the GPU busy)
 The per-kernel durations (`kernel_us`, `roofline.avg_kernel_us`) are HIP events around every 8th launch of THE timed region;
 `value_long` runs without any event record, and `roofline.step_us_without_events` is its time per step (one launch per step: an
 upper bound of the kernel's duration that carries no event overhead).
@@ -132,6 +137,77 @@ def cpu_baseline(mode, N, seconds_target=12.0):
     return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n_streams} streams x {blocks} blocks of {N} samples, mode={mode}, one oracle stream per thread, "
                       f"{dt:.1f} s wall"}
+
+
+def parity_vs_oracle(make, S_, N_, fs_, prepare, params, mono_, first_stream, iir, shift=None, streams=8, blocks=12, dev=None):
+    """The accuracy half of the metric ("frames/s ...; RMS err vs CPU ref"), for ONE leg, outside every timed region: a FRESH
+    processor of exactly the leg's configuration (`make()`: same mode switches, IIR/YIN mode, vocoder path, geometry, batch size
+    -- hence the same kernel builds) takes `blocks` blocks of the leg's synthetic streams through the same device entry point
+    the leg times; `streams` streams sampled across the batch are run through the CPU oracle on the same float32 input.
+    Reports the per-sample RMS / max-abs error of the float32 output, the RMS error relative to the output's RMS, and the
+    number of (stream, block) tracker states -- period, analysis and synthesis marks, beta of the block's last frame -- that
+    differ from the oracle's (discrete decisions; SURVEY.md section 8d "Accuracy")."""
+    import numpy as np
+    import torch
+    from oracle import oracle_py as O
+    from vocoderproject_amd.synth import make_streams
+    q = make()
+    q.set_iir_mode(iir)
+    pitch_on = bool(q.getParameter("pitchBool"))
+    pick = sorted(set(int(round(i * (S_ - 1) / max(streams - 1, 1))) for i in range(min(streams, S_))))
+    x = make_streams(S_, N_ * blocks, fs=fs_, first_stream=first_stream, device=dev)               # [S][3][blocks*N]
+    if shift is not None:
+        for s_ in range(S_):
+            q.setPitchShift(shift if s_ % 2 == 0 else -shift, on=True, stream=s_)
+    xb = x.view(S_, 3, blocks, N_).permute(2, 0, 1, 3).contiguous()                              # [blocks][S][3][N]
+    xm = xb[:, :, 0, :].contiguous() if mono_ else None
+    y = torch.empty((S_, 2, N_), dtype=torch.float32, device=dev)
+    orc = []
+    for s_ in pick:
+        o = O.OracleStream(**dict(params, pitchBool=int(pitch_on), vocBool=int(q.getParameter("vocBool"))))
+        if prepare:
+            o.prepare_explicit(fs_, N_, *prepare)
+        else:
+            o.prepare_to_play(fs_, N_)
+        if shift is not None:
+            o.set_pitch_shift(shift if s_ % 2 == 0 else -shift, on=True)
+        orc.append(o)
+    xh = x[pick].cpu().numpy()
+    got = np.empty((len(pick), 2, N_ * blocks), np.float32)
+    ref = np.empty_like(got)
+    frames = mism = 0
+    st_cur = torch.cuda.current_stream(dev).cuda_stream
+    for b in range(blocks):
+        if mono_:
+            q.process_mono_device(xm[b], y, st_cur)
+        else:
+            q.process_device(xb[b], y, st_cur)
+        got[:, :, b * N_:(b + 1) * N_] = y[pick].cpu().numpy()
+        for i, s_ in enumerate(pick):
+            if mono_:
+                ref[i, :, b * N_:(b + 1) * N_] = orc[i].process_block_mono(np.ascontiguousarray(xh[i, 0, b * N_:(b + 1) * N_]))
+            else:
+                io = np.ascontiguousarray(xh[i, :, b * N_:(b + 1) * N_])
+                orc[i].process_block(io)
+                ref[i, :, b * N_:(b + 1) * N_] = io[:2]
+            if pitch_on:
+                tr = orc[i].traces()
+                if tr and not tr[-1]["gated"]:
+                    st = q.pitch_state(s_)
+                    f = tr[-1]
+                    frames += 1
+                    mism += int((st["period"], st["anMarks"], st["stMarks"], st["beta"]) != (f["period"], f["anMarks"], f["stMarks"], f["beta"]))
+    err = got.astype(np.float64) - ref
+    ref_rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    rms = float(np.sqrt((err ** 2).mean()))
+    out = {"rms_err": rms, "max_abs_err": float(np.abs(err).max()), "rms_rel": rms / ref_rms if ref_rms > 0 else None, "ref_rms": ref_rms,
+           "decision_mismatch_frames": mism, "decision_frames_compared": frames, "bit_identical": bool(np.array_equal(got, ref)),
+           "streams": len(pick), "stream_ids": [first_stream + s_ for s_ in pick], "blocks": blocks, "iir_mode": iir,
+           "kernel_builds": {"pitch": q.pitch_kernel_name() if pitch_on else None,
+                             "vocoder": q.vocoder_kernel_name() if q.getParameter("vocBool") else None},
+           "vs": "oracle/vp_oracle.c (CPU restatement of the reference processBlock), same float32 input, fresh state on both sides"}
+    q.close()
+    return out
 
 
 def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
@@ -247,6 +323,12 @@ def main():
     ap.add_argument("--voc-window", default=None, choices=["512/128", "1024/256"],
                     help="vocoder window/hop: the reference's own 512/128 (default) or the metric's 1024/256 (SURVEY section 8, cfg 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-parity", action="store_true", help="skip the per-leg comparison with the CPU oracle")
+    ap.add_argument("--parity-streams", type=int, default=8, help="streams of each leg's batch that are run through the CPU oracle")
+    ap.add_argument("--parity-blocks", type=int, default=12, help="blocks per stream of that comparison")
+    ap.add_argument("--long-seconds", type=float, default=6.0,
+                    help="value_long: the headline workload again for about this long (so that an outside observer -- the driver's "
+                         "rocm-smi samples -- sees the GPU busy)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -294,18 +376,20 @@ def main():
     if args.cfg5:
         FS, HOP, N = 48000.0, 512, 2048
 
+    # the headline workload's explicit geometry (None: what prepareToPlay picks) and parameters -- shared by the timed processor,
+    # the parity check and the oracle
+    if args.cfg5:
+        hl_prepare, hl_params = (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}
+    else:
+        hl_prepare = (1024, 768, 1024, 256) if args.voc_window == "1024/256" else None   # the pitch geometry prepareToPlay(44100) picks + the metric's vocoder window
+        hl_params = {"lpcVoice": args.lpc_voice} if args.lpc_voice else {}
+
     def make_processor(mode_, S_):
-        if args.cfg5:
-            q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"),
-                                      lpcVoice=48, lpcPitch=48, lpcSynth=30)
-            q.prepareExplicit(FS, N, S_, 2048, 1536, 2048, 512)
+        q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **hl_params)
+        if hl_prepare:
+            q.prepareExplicit(FS, N, S_, *hl_prepare)
         else:
-            kw = {"lpcVoice": args.lpc_voice} if args.lpc_voice else {}
-            q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **kw)
-            if args.voc_window == "1024/256":
-                q.prepareExplicit(FS, N, S_, 1024, 768, 1024, 256)       # the pitch geometry prepareToPlay(44100) picks + the metric's vocoder window
-            else:
-                q.prepareToPlay(FS, N, S_)
+            q.prepareToPlay(FS, N, S_)
         q.set_yin_mode(args.yin)
         q.set_vocoder_path(args.voc_path)
         q.set_overlap(args.overlap)
@@ -423,6 +507,19 @@ def main():
 
     frames_per_step_gpu = S * N * BPS // HOP
 
+    # The accuracy half of the metric for the headline workload (and for the secondary modes timed above), on rank 0, outside the
+    # timed regions: sampled streams of a fresh processor of the same configuration against the CPU oracle.
+    parity = parity_other = parity_shift = None
+    if rank == 0 and not args.no_parity and BPS == 1:
+        def mk_hl():
+            return make_processor(mode, S)
+        pk = dict(dev=dev, streams=args.parity_streams, blocks=min(args.parity_blocks, U))
+        parity = parity_vs_oracle(mk_hl, S, N, FS, hl_prepare, hl_params, mono, rank * S, args.iir, shift=args.shift, **pk)
+        if not args.single_mode:
+            parity_other = parity_vs_oracle(mk_hl, S, N, FS, hl_prepare, hl_params, mono, rank * S, other, shift=args.shift, **pk)
+            if dt_shift == dt_shift:
+                parity_shift = parity_vs_oracle(mk_hl, S, N, FS, hl_prepare, hl_params, mono, rank * S, args.iir, shift=12.0, **pk)
+
     # the batch lives on rank 0; per step root fan-out (scatter_streams), processBlock on every rank, root
     # fan-in (gather_streams).  Double-buffered: step i+1's scatter and step i-1's gather ride RCCL's stream beside step
     # i's kernels (exchange_steps enqueues on torch's CURRENT stream: the processor is handed that same stream).
@@ -468,19 +565,23 @@ def main():
     value_long = None
     if not args.single_mode and BPS == 1:
         p.set_iir_mode(args.iir)
-        kl = max(2000, args.steps)
+        kl = max(2000, args.steps, int(args.long_seconds / max(dt / args.steps, 1e-6)))
         dtl = region(step, kl, 8)
         (dtl,) = max_over_ranks(dtl)
         value_long = {"value": frames_per_step_gpu * kl * n_gpus / dtl, "steps": kl, "ms_per_step": dtl / kl * 1e3}
 
     # The other BASELINE configs at their per-GPU share, so that one driver run (at every N) carries a figure for each of them.
-    def leg(what, mode_, S_, fs_, N_, hop_, prepare, params, steps_, with_exchange=False, blocks=0):
-        q = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **params)
-        if prepare:
-            q.prepareExplicit(fs_, N_, S_, *prepare)
-        else:
-            q.prepareToPlay(fs_, N_, S_)
-        q.set_yin_mode(args.yin)
+    def leg(what, mode_, S_, fs_, N_, hop_, prepare, params, steps_, with_exchange=False, blocks=0, exact_too=True):
+        def mk():
+            q_ = BatchVocoderProcessor(device=local_rank, pitchBool=int(mode_ != "voc"), vocBool=int(mode_ != "pitch"), **params)
+            if prepare:
+                q_.prepareExplicit(fs_, N_, S_, *prepare)
+            else:
+                q_.prepareToPlay(fs_, N_, S_)
+            q_.set_yin_mode(args.yin)
+            return q_
+
+        q = mk()
         q.set_iir_mode(args.iir)
         xl = make_streams(S_, N_ * 4, fs=fs_, first_stream=rank * S_, device=dev).view(S_, 3, 4, N_).permute(2, 0, 1, 3).contiguous()
         yl = torch.empty((S_, 2, N_), dtype=torch.float32, device=dev)
@@ -492,6 +593,16 @@ def main():
                 "kernel_builds": {"pitch": q.pitch_kernel_name() if mode_ != "voc" else None,
                                   "vocoder": q.vocoder_kernel_name() if mode_ != "pitch" else None}}
         out_["hbm_frac_algorithmic"] = out_["alg_bytes_per_step_per_gpu"] / (dtl_ / steps_) / 1e9 / HBM_PEAK_GBS
+        if exact_too:                                  # the bit-identical mode's figure for this configuration
+            q.set_iir_mode(other)
+            ke = max(12, steps_ // 3)
+            dte_ = region(lambda i: q.process_device(xl[i % 4], yl, stream.cuda_stream), ke, 2)
+            (dte_,) = max_over_ranks(dte_)
+            out_[f"value_{other}_mode"] = (S_ * N_ // hop_) * ke * n_gpus / dte_
+            q.set_iir_mode(args.iir)
+        if rank == 0 and not args.no_parity:           # the accuracy half of the metric, in the mode and on the builds just timed
+            out_["parity"] = parity_vs_oracle(mk, S_, N_, fs_, prepare, params, False, rank * S_, args.iir, dev=dev,
+                                              streams=args.parity_streams, blocks=args.parity_blocks)
         if do_exchange and with_exchange:
             out_["exchange"] = exchange_region(q, S_, N_, fs_, hop_, False, max(8, steps_ // 2))
         if blocks > 1:                              # the same blocks handed over `blocks` at a time (vp_process_blocks_device)
@@ -558,6 +669,9 @@ def main():
                        "parallelism": f"streams sharded over {n_gpus} GPU(s), one process per GPU, no data-path collective"},
             "roofline": roof,
             "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items() if v[1]},
+            "parity": parity,
+            f"parity_{other}_mode": parity_other,
+            "parity_pm12_semitone_shift": parity_shift,
             "checksum": float(chk.item()),
             f"value_{other}_mode": (frames_per_step_gpu * k2 * n_gpus / dt_other) if dt_other == dt_other else None,
             "value_8_blocks_per_call": ((S * N * MB // HOP) * k3 * n_gpus / dt_mb) if dt_mb == dt_mb else None,

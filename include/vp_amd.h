@@ -11,8 +11,9 @@
  * Threading: one caller thread per handle (the reference runs processBlock() on one audio
  * thread per instance, PluginProcessor.cpp:203).  Parameters are snapshotted at call entry
  * (the reference reads std::atomic<float> values with load(), :214-230).
- * No allocation happens in vp_process_block*() (reference: all vectors are sized in
- * prepareToPlay, PitchProcess.cpp:95-121).
+ * No allocation happens in any vp_process_*() call (reference: all vectors are sized in
+ * prepareToPlay, PitchProcess.cpp:95-121): vp_prepare_*() and vp_reserve_blocks() are the only
+ * entry points that allocate device memory (vp_debug_alloc_count() counts the allocations).
  */
 #ifndef VP_AMD_H
 #define VP_AMD_H
@@ -132,21 +133,38 @@ int vp_process_block_mono_device(vp_handle *h, const float *d_voice, float *d_ou
 int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_out, int n_blocks, void *hip_stream);
 /* n_blocks consecutive processBlock() calls at once (offline rendering, servers with audio queued up):
  * d_in float [n_blocks][n_streams][3][N], d_out float [n_blocks][n_streams][2][N], i.e. block b's slabs are what
- * vp_process_block_device would take.  Results are identical to n_blocks single calls.  With the pitch corrector alone
- * enabled the blocks run in ONE launch (tracker state and the frame in flight stay on chip between them); with the
- * vocoder alone (LPC orders <= 48, any batch size) groups of up to 16 blocks run as ONE launch of the lane-per-window
- * pipeline -- the window grid carries across blocks, so B blocks are B times the windows, i.e. B times the lanes; every block
- * keeps its own ring ingest, silence gate and output slab (256 streams, 8 blocks per call: 2.1x the single-call throughput,
- * 3x in exact mode).  With BOTH enabled, in VP_IIR_FAST, groups of up to 16 blocks run as one launch of the serial pitch kernel
- * followed by one launch of the pipeline (the pitch kernel ingests the blocks and adds its chunks into a linear accumulator of the
- * call, the pipeline works from a snapshot of the rings and folds that accumulator in when it emits): every decision is the
- * block-by-block path's, the audio equals it to rounding level (the additions into the output accumulator happen chunks-first
- * instead of windows-first; 256 streams, 8 blocks per call: 1.4x the single-call throughput, 10.3 M against 7.3 M frames/s).  In VP_IIR_EXACT the combined plan
- * is issued block by block.  Parameters are read once, at entry. */
+ * vp_process_block_device would take.  Parameters are read once, at entry.  What runs:
+ *  - pitch corrector alone: the blocks run in ONE launch (tracker state and the frame in flight stay on chip between them);
+ *    results identical to n_blocks single calls;
+ *  - vocoder alone (LPC orders <= 48): groups of up to 16 blocks as ONE launch of the lane-per-window pipeline -- the window grid
+ *    carries across blocks, so B blocks are B times the windows, i.e. B times the lanes; every block keeps its own ring ingest,
+ *    silence gate and output slab.  In VP_IIR_EXACT always (the pipeline and the workgroup kernel give the same bits: results
+ *    identical to single calls; 256 streams, 8 blocks per call: 3x the single-call throughput); in VP_IIR_FAST only where
+ *    single-block calls take the pipeline too (VP_VOC_AUTO above 256 streams, or VP_VOC_BATCHED) -- the two implementations'
+ *    tolerance-mode roundings differ, and the output must not depend on how the caller groups blocks;
+ *  - both enabled, VP_IIR_FAST, and single-block calls on the pipeline (same condition): groups of up to 16 blocks as one launch of
+ *    the serial pitch kernel followed by one launch of the pipeline (the pitch kernel ingests the blocks and adds its chunks into a
+ *    linear accumulator of the call, the pipeline works from a snapshot of the rings and folds that accumulator in when it emits):
+ *    every decision and every filter output is the block-by-block path's; the audio equals it to the rounding of the additions
+ *    into the output accumulator, which happen chunks-first instead of windows-first (<= 2e-6 of full scale, tested);
+ *  - anything else (VP_IIR_EXACT with both enabled, per-stream switches that split the batch, ...): block by block.
+ * The two pipeline plans need scratch for the call's windows: vp_reserve_blocks(h, n) sizes it for calls of up to n blocks; a
+ * larger call is carried out in groups of n, and without a reservation these plans fall back to block by block.  Nothing is
+ * allocated here. */
 int vp_process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream);
-/* The same from HOST memory: in float [n_blocks][n_streams][3][N], out float [n_blocks][n_streams][2][N]; one upload,
- * the blocks, one download, synchronises before returning (staging buffers grow on demand; VP_ERR_OOM). */
+/* The same from HOST memory: in float [n_blocks][n_streams][3][N], out float [n_blocks][n_streams][2][N]; upload, the blocks,
+ * download, in groups of as many blocks as vp_reserve_blocks sized the staging buffers for (none reserved: block by block through
+ * the single-block staging buffers of prepare); synchronises before returning. */
 int vp_process_blocks(vp_handle *h, const float *in, float *out, int n_blocks);
+/* Allocation for the multi-block entry points, outside the process calls: scratch of the lane-per-window pipeline for the windows of
+ * min(n_blocks, 16) blocks, the combined plan's ring snapshots / per-block gates / linear accumulator, and host staging for
+ * n_blocks blocks.  After prepare (a new prepare drops the reservation); grows only; synchronises the device.  VP_ERR_OOM.
+ * (The reference sizes everything in prepareToPlay, PitchProcess.cpp:95-121; how many blocks a caller queues per call is not a
+ * prepareToPlay argument, hence the separate entry point.) */
+int vp_reserve_blocks(vp_handle *h, int n_blocks);
+int vp_get_reserved_blocks(const vp_handle *h);
+/* Device allocations (hipMalloc calls) made for this handle since vp_create: constant across any sequence of vp_process_*() calls. */
+long vp_debug_alloc_count(const vp_handle *h);
 
 /* Arithmetic of the two all-pole synthesis filters (VocoderProcess.cpp:277-286, PitchProcess.cpp:307-322).
  * VP_IIR_EXACT (default): the reference's summation order, output bit-identical to the CPU restatement.

@@ -125,7 +125,9 @@ public:
     {
         check(vp_process_blocks_device(h_, dIn, dOut, nBlocks, hipStream), "processBlocksDevice");
     }
-    // the same from host memory (one upload, the blocks, one download)
+    // sizes the multi-block scratch and staging for calls of up to nBlocks blocks: the process calls never allocate (vp_amd.h)
+    void reserveBlocks(int nBlocks) { check(vp_reserve_blocks(h_, nBlocks), "reserveBlocks"); }
+    // the same from host memory (upload, the blocks, download, in groups of the reserved size)
     void processBlocks(const float *in, float *out, int nBlocks) { check(vp_process_blocks(h_, in, out, nBlocks), "processBlocks"); }
     int getLatencySamples() const { return vp_get_latency(h_); }                   // :183
     BufferView bufferView() const

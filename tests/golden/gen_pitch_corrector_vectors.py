@@ -5,6 +5,10 @@ all-pole filter -> st_window overlap-add, over many frames) and its synthesis-wi
 
     python tests/golden/gen_pitch_corrector_vectors.py
 
+CAUTION: this script imports Notebook/methods.py and exec()s two notebook cells straight from the read-only, UNTRUSTED reference
+tree: it runs reference code.  Run it only in the sandboxed build container (it needs /root/reference, which does not exist
+anywhere else); the tests never run it, they read the .npz it wrote.
+
 What it pins (round-2 verdict, item 6): the plugin's pitch-only processBlock() END TO END on steadily voiced streams -- the
 chain of stages, the half-Hann overlap-add of consecutive frames and the frame grid/latency alignment of MyBuffer --, against
 the one multi-frame flow the reference ships in runnable form.  The notebook is "a different parametrisation" (its cell 0 says

@@ -61,8 +61,9 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     poison=True builds the other diagnostic library (-DVP_POISON_LDS: every kernel first fills its LDS with
     NaNs, so a read of LDS the launch has not written fails the parity tests deterministically instead of
     depending on what the previous kernel left on that CU); tests/test_gpu_parity.py runs the suite on it."""
-    lib = os.environ.get("VP_LIB_OUT") or (LIB_STAMPS if stamps else LIB_POISON if poison else LIB)   # (VP_LIB_OUT: experiment builds, tools/ab.sh)
-    if not stamps and not poison and not force and not needs_build():
+    # (VP_LIB_OUT: experiment builds of the PRODUCT library, tools/ab.sh; the diagnostic twins keep their own paths)
+    lib = LIB_STAMPS if stamps else LIB_POISON if poison else (os.environ.get("VP_LIB_OUT") or LIB)
+    if not stamps and not poison and not force and lib == LIB and not needs_build():
         return LIB
     # vp_kernels.hip can be compiled as NUM_TUS translation units side by side (each keeps one group of kernels, -DVP_TU=k),
     # vp_capi.hip is one more; then one link.  (One translation unit takes 90 s, the groups 40 s.)

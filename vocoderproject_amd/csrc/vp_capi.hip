@@ -63,7 +63,9 @@ struct vp_handle {
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
-    float *stageInB = nullptr, *stageOutB = nullptr; int stageBlocks = 0;   // vp_process_blocks: grow-only, [B][S][3|2][N]
+    float *stageInB = nullptr, *stageOutB = nullptr; int stageBlocks = 0;   // vp_process_blocks: [B][S][3|2][N], sized by vp_reserve_blocks
+    int reservedBlocks = 0;                     // vp_reserve_blocks: blocks per call the multi-block scratch is sized for
+    long nAllocs = 0;                           // device allocations made for this handle since vp_create (vp_debug_alloc_count)
     hipStream_t ownStream = nullptr;
     int vocWaves = 8;
     size_t vocLds = 0, pitchLds = 0, ldsMax = 0;
@@ -93,6 +95,14 @@ static int fail_hip(vp_handle *h, hipError_t e, const char *what)
     return VP_ERR_HIP;
 }
 #define HIPCHK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail_hip((h), _e, #call); } while (0)
+
+// every device allocation of a handle goes through here: prepare and vp_reserve_blocks allocate, vp_process_*() never do
+// (include/vp_amd.h; tests/test_gpu_round4.py watches the count across every process entry point)
+static hipError_t vp_malloc(vp_handle *h, void **q, size_t bytes)
+{
+    h->nAllocs += 1;
+    return hipMalloc(q, bytes);
+}
 
 extern "C" int vp_abi_version(void) { return VP_ABI_VERSION; }
 
@@ -203,6 +213,7 @@ static bool voc_o48(int oVmax) { return oVmax > 32 && oVmax <= 48; }
 extern "C" int vp_set_vocoder_path(vp_handle *h, int path)
 {
     if (!h || path < VP_VOC_AUTO || path > VP_VOC_BATCHED) return VP_ERR_INVALID_ARG;
+    if (path != h->vocPath) h->cohortsDirty = true;        // the cohorts are keyed by the order class the pipeline can take (rebuild_cohorts)
     h->vocPath = path;
     return VP_OK;
 }
@@ -295,7 +306,7 @@ static void free_all(vp_handle *h)
     h->bothAllocs.clear(); h->snapV = h->snapS = nullptr; h->gateB = nullptr; h->pLin = nullptr;
     if (h->stageInB) (void)hipFree(h->stageInB);
     if (h->stageOutB) (void)hipFree(h->stageOutB);
-    h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
+    h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0; h->reservedBlocks = 0;
     h->prepared = false;
 }
 
@@ -480,7 +491,7 @@ template <typename T>
 static int dev_alloc(vp_handle *h, T **p, size_t count, bool zero = true)
 {
     void *q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    hipError_t e = vp_malloc(h, &q, std::max<size_t>(count, 1) * sizeof(T));
     if (e != hipSuccess) { h->lastError = "hipMalloc failed"; return VP_ERR_OOM; }
     h->allocs.push_back(q);
     if (zero) HIPCHK(h, hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T)));
@@ -1007,7 +1018,7 @@ extern "C" int vp_process_block_device(vp_handle *h, const float *d_in, float *d
     return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0);
 }
 
-// scratch of the batched vocoder pipeline for `nWin` windows per stream (multi-block launches), grown on demand
+// scratch of the batched vocoder pipeline for `nWin` windows per stream (multi-block launches); called by vp_reserve_blocks only
 static int ensure_v2mb(vp_handle *h, int nWin)
 {
     if (nWin <= h->v2mbWin) return VP_OK;
@@ -1022,7 +1033,7 @@ static int ensure_v2mb(vp_handle *h, int nWin)
     const size_t NWp = (size_t)v.nGroupsMax * 64;
     auto get = [&](auto **p, size_t count) -> bool {
         void *q = nullptr;
-        if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(**p)) != hipSuccess) return false;
+        if (vp_malloc(h, &q, std::max<size_t>(count, 1) * sizeof(**p)) != hipSuccess) return false;
         h->mbAllocs.push_back(q);
         (void)hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(**p));
         *p = (std::remove_reference_t<decltype(**p)> *)q;
@@ -1052,6 +1063,9 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX) return VP_OK;
     auto &co = h->cohorts[0];
     if (!co.vocOn || co.pitchOn || !h->v2.xT || h->vocPath == VP_VOC_WORKGROUP) return VP_OK;
+    // VP_IIR_FAST: the pipeline's and the workgroup kernel's tolerance-mode roundings differ, so the plan only runs where single-block
+    // calls take the pipeline too (the output must not depend on how the caller groups blocks); VP_IIR_EXACT: both give the same bits
+    if (h->iirMode == VP_IIR_FAST && !voc_pipeline_wanted(h)) return VP_OK;
     if (co.oVmax > V2_ORDER_MAX || co.oSmax > VP_ORDER_MAX_SYNTH || co.oVmax < 2 || co.oSmax < 2) return VP_OK;
     // vp_k_v2_mb_ola_emit keeps outSize doubles in dynamic LDS: a geometry beyond its ceiling takes the block-by-block plan
     if ((size_t)g.outSize * sizeof(double) > (size_t)VP_V2_MB_LDS_MAX) return VP_OK;
@@ -1070,8 +1084,7 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     for (int b = 1; b < nb; b++)
         if (mb.nWin[b] > 0 && b * g.N + mb.vStart[b] != mb.vStart[0] + mb.first[b] * g.h) return VP_OK;
     if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
-    int rc = ensure_v2mb(h, NWs);
-    if (rc) return rc;
+    if (NWs > h->v2mbWin) return VP_OK;                                      // beyond what vp_reserve_blocks sized: no allocation here
     h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
     VpCall c;
     memset(&c, 0, sizeof c);
@@ -1104,7 +1117,7 @@ static int ensure_both(vp_handle *h)
     const VpGeom &g = h->g;
     auto get = [&](auto **p, size_t count) -> bool {
         void *q = nullptr;
-        if (hipMalloc(&q, count * sizeof(**p)) != hipSuccess) return false;
+        if (vp_malloc(h, &q, count * sizeof(**p)) != hipSuccess) return false;
         h->bothAllocs.push_back(q);
         (void)hipMemset(q, 0, count * sizeof(**p));
         *p = (std::remove_reference_t<decltype(**p)> *)q;
@@ -1134,7 +1147,9 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     const VpGeom &g = h->g;
     if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX || h->iirMode != VP_IIR_FAST) return VP_OK;
     auto &co = h->cohorts[0];
-    if (!co.vocOn || !co.pitchOn || !h->v2.xT || h->vocPath == VP_VOC_WORKGROUP) return VP_OK;
+    // only where single-block calls run the pipeline too (VP_VOC_AUTO: batches above 256 streams; VP_VOC_BATCHED): the vocoder's
+    // arithmetic must not depend on how the caller groups blocks (voc_auto_batched: "decided ONCE per prepare")
+    if (!co.vocOn || !co.pitchOn || !voc_pipeline_wanted(h)) return VP_OK;
     if (co.oVmax > V2_ORDER_MAX || co.oSmax > VP_ORDER_MAX_SYNTH || co.oVmax < 2 || co.oSmax < 2) return VP_OK;
     if ((size_t)g.outSize * sizeof(double) > (size_t)VP_V2_MB_LDS_MAX) return VP_OK;
     if (h->yinMode == VP_YIN_FFT && g.fftLog > 0) return VP_OK;
@@ -1152,9 +1167,7 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     for (int b = 1; b < nb; b++)
         if (mb.nWin[b] > 0 && b * g.N + mb.vStart[b] != mb.vStart[0] + mb.first[b] * g.h) return VP_OK;
     if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
-    int rc = ensure_v2mb(h, NWs);
-    if (rc) return rc;
-    if ((rc = ensure_both(h)) != VP_OK) return rc;
+    if (NWs > h->v2mbWin || !h->pLin) return VP_OK;                          // not reserved (vp_reserve_blocks): block by block, no allocation here
     h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
     struct Poison { vp_handle *h; bool armed; ~Poison() { if (armed) h->poisoned = true; } } guard{h, true};
     HIPCHK(h, hipMemcpyAsync(h->snapV, h->d.voiceRing, (size_t)g.S * g.inSize * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1234,7 +1247,7 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     if (!mono && n_blocks > 1) {                               // vocoder-only plan on the batched pipeline: groups of blocks per launch
         int b = 0;
         while (b < n_blocks) {
-            const int nb = std::min(n_blocks - b, V2_MB_MAX);
+            const int nb = std::min(n_blocks - b, std::min(V2_MB_MAX, std::max(h->reservedBlocks, 1)));   // groups the reserved scratch holds
             bool done = false;
             rc = process_voc_blocks(h, d_in + b * nIn, d_out + b * nOut, nb, (hipStream_t)hip_stream, &done);
             if (rc) return rc;
@@ -1297,12 +1310,44 @@ extern "C" int vp_process_blocks(vp_handle *h, const float *in, float *out, int 
     if (!h->prepared) return VP_ERR_NOT_PREPARED;
     if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     const size_t nIn = (size_t)h->g.S * 3 * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
-    if (n_blocks > h->stageBlocks) {
+    // groups of as many blocks as the staging buffers hold (vp_reserve_blocks); none reserved: block by block through the
+    // single-block staging of prepare.  No allocation here.
+    for (int b = 0; b < n_blocks; ) {
+        const int nb = std::min(n_blocks - b, std::max(h->stageBlocks, 1));
+        float *sIn = h->stageBlocks ? h->stageInB : h->stageIn, *sOut = h->stageBlocks ? h->stageOutB : h->stageOut;
+        HIPCHK(h, hipMemcpyAsync(sIn, in + b * nIn, nIn * nb * sizeof(float), hipMemcpyHostToDevice, h->ownStream));
+        int rc = vp_process_blocks_device(h, sIn, sOut, nb, (void *)h->ownStream);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(out + b * nOut, sOut, nOut * nb * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
+        b += nb;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->ownStream));
+    return VP_OK;
+}
+
+// Sizes everything the multi-block entry points need for calls of up to n_blocks blocks.  The ONLY allocation site besides prepare.
+extern "C" int vp_reserve_blocks(vp_handle *h, int n_blocks)
+{
+    if (!h || n_blocks < 1) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());                                        // nothing in flight may still use what is replaced below
+    const VpGeom &g = h->g;
+    const int nb = std::min(n_blocks, V2_MB_MAX);
+    if (h->v2.xT && nb >= 2 && (size_t)g.outSize * sizeof(double) <= (size_t)VP_V2_MB_LDS_MAX) {
+        // the lane-per-window pipeline over the windows of nb blocks (vocoder-only plan), and the combined plan's ring snapshots,
+        // per-block gates and linear accumulator (both processes, VP_IIR_FAST) -- whatever the switches are now: they may change later
+        int rc = ensure_v2mb(h, nb * h->nWinMax);
+        if (rc) return rc;
+        if ((rc = ensure_both(h)) != VP_OK) return rc;
+    }
+    if (n_blocks > h->stageBlocks) {                                          // host staging of vp_process_blocks
+        const size_t nIn = (size_t)g.S * 3 * g.N, nOut = (size_t)g.S * 2 * g.N;
         if (h->stageInB) (void)hipFree(h->stageInB);
         if (h->stageOutB) (void)hipFree(h->stageOutB);
         h->stageInB = h->stageOutB = nullptr; h->stageBlocks = 0;
-        if (hipMalloc((void **)&h->stageInB, nIn * n_blocks * sizeof(float)) != hipSuccess ||
-            hipMalloc((void **)&h->stageOutB, nOut * n_blocks * sizeof(float)) != hipSuccess) {
+        if (vp_malloc(h, (void **)&h->stageInB, nIn * n_blocks * sizeof(float)) != hipSuccess ||
+            vp_malloc(h, (void **)&h->stageOutB, nOut * n_blocks * sizeof(float)) != hipSuccess) {
             if (h->stageInB) (void)hipFree(h->stageInB);
             h->stageInB = nullptr;
             h->lastError = "out of device memory for the block staging buffers";
@@ -1310,13 +1355,12 @@ extern "C" int vp_process_blocks(vp_handle *h, const float *in, float *out, int 
         }
         h->stageBlocks = n_blocks;
     }
-    HIPCHK(h, hipMemcpyAsync(h->stageInB, in, nIn * n_blocks * sizeof(float), hipMemcpyHostToDevice, h->ownStream));
-    int rc = vp_process_blocks_device(h, h->stageInB, h->stageOutB, n_blocks, (void *)h->ownStream);
-    if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(out, h->stageOutB, nOut * n_blocks * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
-    HIPCHK(h, hipStreamSynchronize(h->ownStream));
+    h->reservedBlocks = std::max(h->reservedBlocks, n_blocks);
+    HIPCHK(h, hipDeviceSynchronize());                                        // the zero fills (null stream) are complete before any launch
     return VP_OK;
 }
+extern "C" int vp_get_reserved_blocks(const vp_handle *h) { return (h && h->prepared) ? h->reservedBlocks : VP_ERR_NOT_PREPARED; }
+extern "C" long vp_debug_alloc_count(const vp_handle *h) { return h ? h->nAllocs : -1; }
 
 extern "C" int vp_process_block(vp_handle *h, const float *in, float *out)
 {

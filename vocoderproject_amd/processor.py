@@ -102,6 +102,10 @@ def load_library():
     if hasattr(L, "vp_set_overlap"):
         L.vp_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.vp_get_overlap.argtypes = [C.c_void_p]
+    L.vp_reserve_blocks.argtypes = [C.c_void_p, C.c_int]
+    L.vp_get_reserved_blocks.argtypes = [C.c_void_p]
+    L.vp_debug_alloc_count.argtypes = [C.c_void_p]
+    L.vp_debug_alloc_count.restype = C.c_long
     L.vp_set_time_parallel.argtypes = [C.c_void_p, C.c_int]
     L.vp_get_time_parallel.argtypes = [C.c_void_p]
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
@@ -285,7 +289,17 @@ class BatchVocoderProcessor:
         if stream is None:
             import torch
             stream = torch.cuda.current_stream(d_voice.device).cuda_stream
+        self.reserve_blocks(B)
         self._chk(self.L.vp_process_blocks_mono_device(self.h, d_voice.data_ptr(), d_out.data_ptr(), int(B), C.c_void_p(stream)))
+
+    def reserve_blocks(self, n_blocks):
+        """vp_reserve_blocks: size the multi-block scratch and staging for calls of up to n_blocks blocks (the C process calls never
+        allocate; the process_blocks* methods of this mirror call it for the caller when a call is larger than what is reserved)."""
+        if int(n_blocks) > self.L.vp_get_reserved_blocks(self.h):
+            self._chk(self.L.vp_reserve_blocks(self.h, int(n_blocks)))
+
+    def alloc_count(self):
+        return int(self.L.vp_debug_alloc_count(self.h))
 
     def process_device(self, d_in, d_out, stream=None):
         """Device-resident, asynchronous: torch CUDA(HIP) float32 tensors [S][3][N] -> [S][2][N]."""
@@ -306,6 +320,7 @@ class BatchVocoderProcessor:
         if stream is None:
             import torch
             stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        self.reserve_blocks(B)
         self._chk(self.L.vp_process_blocks_device(self.h, d_in.data_ptr(), d_out.data_ptr(), int(B), C.c_void_p(stream)))
 
     def process_blocks(self, x):
@@ -313,6 +328,7 @@ class BatchVocoderProcessor:
         process() (pitch corrector alone: one launch; used by the offline front end)."""
         assert x.dtype == np.float32 and x.flags.c_contiguous and x.ndim == 4 and x.shape[1:] == (self.n_streams, 3, self.N), x.shape
         out = np.empty((x.shape[0], self.n_streams, 2, self.N), np.float32)
+        self.reserve_blocks(x.shape[0])
         self._chk(self.L.vp_process_blocks(self.h, x.ctypes.data, out.ctypes.data, int(x.shape[0])))
         return out
 
