@@ -83,7 +83,8 @@ def kernel_source_hash():
     h = hashlib.sha256()
     for rel in ("vocoderproject_amd/csrc/vp_kernels.hip", "vocoderproject_amd/csrc/vp_filters.inc", "vocoderproject_amd/csrc/vp_vocoder_wg.inc",
                 "vocoderproject_amd/csrc/vp_pitch.inc", "vocoderproject_amd/csrc/vp_voc2.hip", "vocoderproject_amd/csrc/vp_common.h",
-                "vocoderproject_amd/csrc/vp_kernels.h", "vocoderproject_amd/csrc/vp_voc2.h", "vocoderproject_amd/build.py"):
+                "vocoderproject_amd/csrc/vp_kernels.h", "vocoderproject_amd/csrc/vp_voc2.h", "vocoderproject_amd/csrc/vp_stft.hip",
+                "vocoderproject_amd/csrc/vp_stft.h", "vocoderproject_amd/build.py"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -18,9 +18,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libvp_amd.so")
-SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_capi.hip"]
+SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_stft.hip", "vp_capi.hip"]
 PARTS = ["vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc"]      # included by vp_kernels.hip
-DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h"]
+DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h", "vp_stft.h"]
 ARCH = "gfx950"
 NUM_TUS = 5          # groups of kernels in vp_kernels.hip (VP_TU)
 
@@ -84,6 +84,7 @@ def build(force=False, verbose=False, stamps=False, poison=False):
     with tempfile.TemporaryDirectory(prefix="vp_build_") as tmp:
         jobs = [(os.path.join(CSRC, "vp_kernels.hip"), os.path.join(tmp, f"k{k}.o"), [f"-DVP_TU={k}"]) for k in groups]
         jobs.append((os.path.join(CSRC, "vp_voc2.hip"), os.path.join(tmp, "voc2.o"), []))     # the batched vocoder pipeline (includes vp_kernels.hip's helpers)
+        jobs.append((os.path.join(CSRC, "vp_stft.hip"), os.path.join(tmp, "stft.o"), []))     # the fused STFT round trip (self-contained)
         jobs.append((os.path.join(CSRC, "vp_capi.hip"), os.path.join(tmp, "capi.o"), []))
 
         def compile_one(job):
@@ -93,7 +94,8 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             cmd = common + extra + ["-c", src, "-o", obj]
             hsh = hashlib.sha256((hipcc_version() + " ".join(cmd[:-1]).replace(tmp, "")).encode())
             deps = {"vp_kernels.hip": ["vp_kernels.hip", "vp_common.h"] + PARTS,
-                    "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"] + PARTS}.get(os.path.basename(src))
+                    "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"] + PARTS,
+                    "vp_stft.hip": ["vp_stft.hip", "vp_stft.h"]}.get(os.path.basename(src))
             if deps is None:
                 deps = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.basename(src), os.path.join(ROOT, "include", "vp_amd.h")]
             for dep in deps:

@@ -1,0 +1,412 @@
+// vp_stft.hip -- the fused STFT round trip for gfx950: Hann windowing, FFT, [per-bin spectral stage], inverse FFT and overlap-add
+// in ONE kernel, one frame per WAVEFRONT, the transform's butterflies in registers.
+//
+// NO reference counterpart (the reference contains no FFT, no STFT and no phase vocoder: SURVEY.md section 0).  These are the
+// kernels BASELINE.json's north_star lists ("Hann windowing, batched FFT/iFFT, per-bin phase unwrap/accumulate and overlap-add ...
+// one frame per wavefront with samples staged in LDS"); they are checked against numpy.fft and a build-authored NumPy restatement
+// of the phase-vocoder stage (tests/stft_reference.py) -- parity unpinned by nature -- and reported apart from the metric.
+//
+// Shape of the computation (F = 1024, hop = 256; F = 128 P in general, P = complex points per lane = 8):
+//   * a workgroup = VP_STFT_WAVES (4) wavefronts owns a RUN of consecutive rounds of one stream; in a round wavefront w takes frame
+//     4 round + w.  Its 1024 real samples are read straight from HBM/L2 (one aligned float2 per lane and register: consecutive frames
+//     overlap by 3/4, the re-reads hit L2), windowed and packed as 512 complex points z[n] = x[2n] + i x[2n+1], n = lane + 64 r.
+//   * 512-point complex FFT in registers: three radix-8 steps (dft8: 56 fp64 operations on 8 points held by one lane) with two
+//     exchanges through a wavefront-private 8 KB LDS buffer between them -- decimation in time in the "autosort" order, so input
+//     AND output are in natural order (lane = index mod 64, register = index div 64): no bit reversal anywhere.  The exchange
+//     addresses are skewed so that every ds_write_b128 / ds_read_b128 lane group hits distinct banks (tools/stft_fft_model.py
+//     replays the index algebra and the bank model of MI355X_MICROARCH.md: 0 conflicts).  No barrier inside a transform: a
+//     wavefront's LDS operations execute in order.
+//   * real-input split: X[k] = E[k] + W^k O[k] needs Z[k] and Z[N - k]; lane j owns the pairs k = 64 q + j, q < 4, and fetches the
+//     partners from lane 64 - j's upper registers (a half exchange: 4 values per lane).  The spectral stage works on the pair
+//     in registers: identity (plus an optional magnitude dump) or the phase-vocoder pitch shift below.  Merge, half exchange back,
+//     conjugate, the SAME forward transform again (inverse = conj FFT conj), window * 1/N * overlap-add normalisation.
+//   * overlap-add in LDS, deterministic: every wavefront parks its windowed output frame (f32) in its own exchange buffer, one
+//     barrier, then the workgroup adds, for every output sample of the round's hops, the frames that cover it IN FRAME ORDER onto
+//     a carry of the hops the previous round left incomplete, writes each finished sample to HBM exactly once and keeps the
+//     unfinished hops as the new carry.  No frame scratch in HBM, no second kernel, no atomics: HBM traffic = input once (+ L2
+//     re-reads) + output once.
+//   * runs: with few streams a stream is cut into runs of rounds so that the grid fills the chip; a run recomputes the
+//     ceil((O - 1) / 4) rounds in front of it with stores suppressed, which rebuilds exactly the carry the previous run ends with
+//     -- the additions happen in the same order, so the output does not depend on the partition (tested).
+//
+// Phase-vocoder stage (template PV; "per-bin phase unwrap/accumulate", north_star; the classic analysis/synthesis pitch shifter):
+// per frame and bin k: magnitude and phase; phase advance against the previous frame minus the bin's nominal advance, wrapped to
+// (-pi, pi] (the unwrap) -> true frequency; bins move to round(k ratio), magnitudes of bins that land together add, the frequency
+// scales by the ratio; the synthesis phase accumulates the scaled advance frame after frame.  A workgroup then owns a whole
+// stream (the accumulator is a recurrence over frames); inside a round the four frames' increments are summed in frame order.
+#include <hip/hip_runtime.h>
+
+#include "vp_stft.h"
+
+#define WAVE 64
+#define NWV VP_STFT_WAVES
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) d2 lds_d2;
+typedef __attribute__((address_space(3))) f2 lds_f2;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) double lds_f64;
+
+// LDS operations of one wavefront execute in order; this only keeps the COMPILER from moving a lane's read of what another lane
+// wrote across that write (no instruction is emitted for a wavefront-scope fence).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct C8 { double re[8], im[8]; };
+
+// 4-point DFT, natural order in and out
+#define VP_DFT4(R0, I0, R1, I1, R2, I2, R3, I3, OR0, OI0, OR1, OI1, OR2, OI2, OR3, OI3) do { \
+        const double e0r = (R0) + (R2), e0i = (I0) + (I2), e1r = (R0) - (R2), e1i = (I0) - (I2); \
+        const double f0r = (R1) + (R3), f0i = (I1) + (I3), gr = (R1) - (R3), gi = (I1) - (I3); \
+        OR0 = e0r + f0r; OI0 = e0i + f0i; OR2 = e0r - f0r; OI2 = e0i - f0i; \
+        OR1 = e1r + gi;  OI1 = e1i - gr;  OR3 = e1r - gi;  OI3 = e1i + gr; } while (0)
+
+// 8-point DFT of the lane's eight registers, natural order in and out: one radix-2 step (the odd half turned by W8^n), two DFT4s
+__device__ __forceinline__ void dft8(C8 &z)
+{
+    const double h = 0.70710678118654752440;
+    double ar[4], ai[4], br[4], bi[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        ar[t] = z.re[t] + z.re[t + 4]; ai[t] = z.im[t] + z.im[t + 4];
+        br[t] = z.re[t] - z.re[t + 4]; bi[t] = z.im[t] - z.im[t + 4];
+    }
+    const double t1r = (br[1] + bi[1]) * h, t1i = (bi[1] - br[1]) * h;          // b1 W8
+    const double t2r = bi[2], t2i = -br[2];                                      // b2 (-i)
+    const double t3r = (bi[3] - br[3]) * h, t3i = -(br[3] + bi[3]) * h;         // b3 W8^3
+    VP_DFT4(ar[0], ai[0], ar[1], ai[1], ar[2], ai[2], ar[3], ai[3], z.re[0], z.im[0], z.re[2], z.im[2], z.re[4], z.im[4], z.re[6], z.im[6]);
+    VP_DFT4(br[0], bi[0], t1r, t1i, t2r, t2i, t3r, t3i, z.re[1], z.im[1], z.re[3], z.im[3], z.re[5], z.im[5], z.re[7], z.im[7]);
+}
+
+// z[r] *= tw[r], r = 1..7 (tw[0] = 1)
+__device__ __forceinline__ void twiddle7(C8 &z, const d2 (&tw)[8])
+{
+#pragma unroll
+    for (int r = 1; r < 8; r++) {
+        const double xr = z.re[r], xi = z.im[r];
+        z.re[r] = __builtin_fma(xr, tw[r].x, -(xi * tw[r].y));
+        z.im[r] = __builtin_fma(xr, tw[r].y, xi * tw[r].x);
+    }
+}
+
+// Per-lane constants of the 512-point transform: exchange addresses (units of 16 bytes inside the wavefront's buffer) and twiddles
+struct FftLane {
+    int w1, r1, w2;            // bases of exchange 1's stores and loads, exchange 2's stores
+    int r2[8];                 // exchange 2's loads (the skew is a rotation: not affine in the register index)
+    d2 tw1[8], tw2[8];
+};
+
+__device__ __forceinline__ void fft_lane_init(FftLane &L, int lane, const double *tw1, const double *tw2)
+{
+    const int a = lane & 7, hi = lane >> 3;
+    // exchange 1: lane (a, m0 = hi) register j0 -> A1 = a + 8 (j0 & 1) + 16 (m0 + 8 (j0 >> 1)); read by lane (a, j0 = hi), register m0
+    L.w1 = a + 16 * hi;
+    L.r1 = a + 8 * (hi & 1) + 128 * (hi >> 1);
+    // exchange 2: lane (a, j0 = hi) register j1 -> B = ((a + j0) & 7) + 8 (j1 & 1) + 16 (j0 + 8 (j1 >> 1)); read by lane j = j0 + 8 j1, register a
+    L.w2 = ((a + hi) & 7) + 16 * hi;
+#pragma unroll
+    for (int r = 0; r < 8; r++) L.r2[r] = ((r + a) & 7) + 8 * (hi & 1) + 16 * (a + 8 * (hi >> 1));
+    const d2 *t1 = (const d2 *)tw1 + lane * 8, *t2 = (const d2 *)tw2 + lane * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { L.tw1[r] = t1[r]; L.tw2[r] = t2[r]; }
+}
+
+// 512-point complex FFT of one wavefront: natural order in (z.re[r] <-> index lane + 64 r) and out.
+//   step A: DFT8 over m1 (n = a + 8 m0 + 64 m1);  step B: twiddle W_64^(m0 j0), DFT8 over m0;  step C: twiddle W_512^(a j), DFT8 over a
+__device__ __forceinline__ void fft512(C8 &z, lds_d2 *buf, const FftLane &L)
+{
+    dft8(z);
+    wave_sync();
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0++) buf[L.w1 + 8 * (j0 & 1) + 128 * (j0 >> 1)] = d2{z.re[j0], z.im[j0]};
+    wave_sync();
+#pragma unroll
+    for (int m0 = 0; m0 < 8; m0++) { const d2 v = buf[L.r1 + 16 * m0]; z.re[m0] = v.x; z.im[m0] = v.y; }
+    twiddle7(z, L.tw1);
+    dft8(z);
+    wave_sync();
+#pragma unroll
+    for (int j1 = 0; j1 < 8; j1++) buf[L.w2 + 8 * (j1 & 1) + 128 * (j1 >> 1)] = d2{z.re[j1], z.im[j1]};
+    wave_sync();
+#pragma unroll
+    for (int a = 0; a < 8; a++) { const d2 v = buf[L.r2[a]]; z.re[a] = v.x; z.im[a] = v.y; }
+    twiddle7(z, L.tw2);
+    dft8(z);
+}
+
+// exchange buffers / output slots, overlap-add carry (F - hop floats), rounded up to 16 bytes
+__host__ __device__ static inline size_t stft_lds_base(int F, int hop)
+{
+    return (((size_t)NWV * 8192 + (size_t)(F - hop) * sizeof(float)) + 15) & ~(size_t)15;
+}
+size_t vp_stft_lds_bytes(int F, int hop) { return stft_lds_base(F, hop); }
+static size_t stft_pv_lds_bytes(int F)
+{
+    const size_t nb = (size_t)F / 2 + 1;
+    // previous-frame phases [NWV + 1][nb], analysis (magnitude, frequency) [NWV][nb][2], phase increments [NWV][nb], accumulator [nb]
+    return ((NWV + 1) * nb + NWV * nb * 2 + NWV * nb + nb) * sizeof(double);
+}
+
+int vp_stft_supported(int F, int hop)
+{
+    return F == 1024 && hop > 0 && F % hop == 0 && F / hop >= 2 && F / hop <= 16;
+}
+
+#define VP_TWO_PI 6.283185307179586476925286766559
+
+// the wavefront's phase-vocoder work arrays (PV builds only)
+struct PvLds {
+    lds_f64 *phPrev;           // [NWV + 1][nb]  slot w + 1: frame of wavefront w this round; slot 0: the previous round's last frame
+    lds_d2 *ana;               // [NWV][nb]      (magnitude, true frequency in bins) of this wavefront's frame
+    lds_f64 *inc;              // [NWV][nb]      synthesis phase increment of each wavefront's frame
+    lds_f64 *sum;              // [nb]           synthesis phase accumulator after the previous round
+};
+
+template <bool PV>
+__global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = blockIdx.y, run = blockIdx.x;
+    constexpr int N = 512;                                                     // complex points = F / 2
+    const int F = A.F, hop = A.hop, O = A.O, T = A.T;
+    lds_d2 *xb = (lds_d2 *)smem + wv * 512;                                    // this wavefront's exchange buffer ...
+    lds_f32 *slots = (lds_f32 *)smem;                                          // ... whose first F floats double as its output slot (slot w at w * 2048)
+    lds_f32 *carry = (lds_f32 *)smem + NWV * 2048;                             // [(O - 1) hop]
+    PvLds pv;
+    if (PV) {
+        const int nb = N + 1;
+        lds_f64 *p = (lds_f64 *)smem + (stft_lds_base(F, hop) / 8);
+        pv.phPrev = p; p += (NWV + 1) * nb;
+        pv.ana = (lds_d2 *)p + (size_t)wv * nb; p += NWV * nb * 2;
+        pv.inc = p; p += NWV * nb;
+        pv.sum = p;
+    }
+
+    // per-lane constants, once per wavefront: window values of the lane's 16 samples, transform constants, split twiddles
+    FftLane L;
+    fft_lane_init(L, lane, A.tw1, A.tw2);
+    d2 wa[8];                                                                  // (w[2n], w[2n + 1]), n = lane + 64 r
+    d2 ws[4];                                                                  // W_1024^(64 q + lane)
+#pragma unroll
+    for (int r = 0; r < 8; r++) wa[r] = ((const d2 *)A.win)[lane + 64 * r];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ws[q] = ((const d2 *)A.tws)[lane * 4 + q];
+    const int pl = (64 - lane) & 63;                                           // the lane that holds the mirror bins
+    const bool lane0 = lane == 0;
+
+    for (int i = tid; i < F - hop; i += 64 * NWV) carry[i] = 0.f;
+    if (PV) {
+        const int nb = N + 1;
+        for (int i = tid; i < nb; i += 64 * NWV) { pv.phPrev[i] = 0.0; pv.sum[i] = 0.0; }
+    }
+    __syncthreads();
+
+    const int rFirst = run * A.roundsPerRun;                                   // first round whose hops this workgroup stores
+    const int r0 = max(0, rFirst - (run > 0 ? A.haloRounds : 0));
+    const int r1 = min(rFirst + A.roundsPerRun, A.nRounds);
+    const float *xs = A.in + (size_t)s * T;
+    for (int rd = r0; rd < r1; rd++) {
+        const int f = rd * NWV + wv;
+        const bool live = f < A.nFrames;                                       // (wavefront-uniform)
+        C8 z;
+        double Pr[4], Pi[4];                                                   // mirror bins Z[N - k] of the lane's pairs
+        double xkr[4], xki[4], xmr[4], xmi[4];                                 // X[k], X[N - k] of the lane's pairs
+        if (live) {
+            const float *x = xs + (size_t)f * hop;
+            if (A.aligned) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const f2 v = *(const f2 *)(x + 2 * (lane + 64 * r));
+                    z.re[r] = (double)v.x * wa[r].x; z.im[r] = (double)v.y * wa[r].y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float v0 = x[2 * (lane + 64 * r)], v1 = x[2 * (lane + 64 * r) + 1];
+                    z.re[r] = (double)v0 * wa[r].x; z.im[r] = (double)v1 * wa[r].y;
+                }
+            }
+            fft512(z, xb, L);
+            // ---- split: lane j owns the pairs (k, N - k), k = 64 q + j, q < 4; the partners sit in lane 64 - j's registers 7 - q
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 4; u++) xb[u * 64 + lane] = d2{z.re[4 + u], z.im[4 + u]};
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const d2 v = xb[(3 - q) * 64 + pl]; Pr[q] = v.x; Pi[q] = v.y; }
+            if (lane0) {                                                       // lane 0's mirrors are its own: N - 64 q = 64 (8 - q); slot 0 takes k = N / 2
+                Pr[0] = z.re[4]; Pi[0] = z.im[4]; Pr[1] = z.re[7]; Pi[1] = z.im[7];
+                Pr[2] = z.re[6]; Pi[2] = z.im[6]; Pr[3] = z.re[5]; Pi[3] = z.im[5];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double e2r = z.re[q] + Pr[q], e2i = z.im[q] - Pi[q];     // Z[k] + conj Z[N - k]
+                const double dr = z.re[q] - Pr[q], di = z.im[q] + Pi[q];       // Z[k] - conj Z[N - k]
+                const double ur = __builtin_fma(dr, ws[q].x, -(di * ws[q].y)), ui = __builtin_fma(dr, ws[q].y, di * ws[q].x);   // W^k (.)
+                xkr[q] = 0.5 * (e2r + ui); xki[q] = 0.5 * (e2i - ur);          // X[k]     = E + W^k O
+                xmr[q] = 0.5 * (e2r - ui); xmi[q] = -0.5 * (e2i + ur);         // X[N - k] = conj(E - W^k O)
+            }
+            if (lane0) {                                                       // k = 0: X[0] and X[N] (both real) share Z[0]; k = N / 2: X = conj Z
+                xkr[0] = z.re[0] + z.im[0]; xki[0] = 0.0;                      // X[0]
+                xmr[0] = z.re[0] - z.im[0]; xmi[0] = 0.0;                      // X[N]   (kept in the pair's mirror slot; X[N/2] in Pr/Pi[0])
+                Pi[0] = -Pi[0];                                                // X[N/2] = conj Z[N/2]
+            }
+            if (A.mag) {                                                       // |X[k]|, k <= N, natural order
+                float *m = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = 64 * q + lane;
+                    m[k] = (float)sqrt(xkr[q] * xkr[q] + xki[q] * xki[q]);
+                    m[N - k] = (float)sqrt(xmr[q] * xmr[q] + xmi[q] * xmi[q]);          // (lane 0, q = 0: X[N] sits in the mirror slot)
+                }
+                if (lane0) m[N / 2] = (float)sqrt(Pr[0] * Pr[0] + Pi[0] * Pi[0]);
+            }
+        }
+        if (PV) {
+            // ---- phase-vocoder stage.  Bins of this lane: k = 64 q + lane and N - k (q < 4); lane 0 also holds 0, N and N / 2.
+            const int nb = N + 1;
+            const double expct = VP_TWO_PI / (double)O;                        // nominal phase advance of bin 1 per hop
+            double ph[9];
+            int kb[9];
+            double mg[9];
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    kb[2 * q] = 64 * q + lane; kb[2 * q + 1] = N - kb[2 * q];
+                    mg[2 * q] = sqrt(xkr[q] * xkr[q] + xki[q] * xki[q]); ph[2 * q] = atan2(xki[q], xkr[q]);
+                    mg[2 * q + 1] = sqrt(xmr[q] * xmr[q] + xmi[q] * xmi[q]); ph[2 * q + 1] = atan2(xmi[q], xmr[q]);
+                }
+                kb[8] = N / 2; mg[8] = sqrt(Pr[0] * Pr[0] + Pi[0] * Pi[0]); ph[8] = atan2(Pi[0], Pr[0]);      // lane 0 only
+#pragma unroll
+                for (int e = 0; e < 9; e++) if (e < 8 || lane0) pv.phPrev[(wv + 1) * nb + kb[e]] = ph[e];
+            }
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 9; e++) {
+                    if (e == 8 && !lane0) continue;
+                    const int k = kb[e];
+                    double d = ph[e] - pv.phPrev[wv * nb + k] - (double)k * expct;
+                    d -= VP_TWO_PI * rint(d * (1.0 / VP_TWO_PI));              // the unwrap: deviation from the nominal advance in (-pi, pi]
+                    pv.ana[k] = d2{mg[e], (double)k + d * ((double)O * (1.0 / VP_TWO_PI))};   // true frequency in bins
+                }
+                wave_sync();
+                // bins move to floor(k ratio + 0.5): synthesis bin kk gathers the analysis bins that land on it, in increasing k
+#pragma unroll
+                for (int e = 0; e < 9; e++) {
+                    if (e == 8 && !lane0) continue;
+                    const int kk = kb[e];
+                    const int kc = (int)((double)kk / A.pvRatio);
+                    double sm = 0.0, sf = 0.0;
+                    for (int k = max(kc - 2, 0); k <= min(kc + 2, N); k++) {
+                        if ((int)floor((double)k * A.pvRatio + 0.5) == kk) { const d2 v = pv.ana[k]; sm += v.x; sf = v.y * A.pvRatio; }
+                    }
+                    mg[e] = sm;
+                    pv.inc[wv * nb + kk] = expct * sf;                          // phase advance of the synthesis bin over one hop
+                }
+            }
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 9; e++) {
+                    if (e == 8 && !lane0) continue;
+                    const int kk = kb[e];
+                    double sp = pv.sum[kk];
+                    for (int w = 0; w <= wv; w++) sp += pv.inc[w * nb + kk];   // frames of the round in order (frames beyond the stream's last add nothing: they are never live)
+                    ph[e] = sp;
+                    double sn, cs;
+                    sincos(sp, &sn, &cs);
+                    const double re = mg[e] * cs, im = mg[e] * sn;
+                    if (e == 8) { Pr[0] = re; Pi[0] = im; }
+                    else if (e & 1) { xmr[e >> 1] = re; xmi[e >> 1] = im; }
+                    else { xkr[e >> 1] = re; xki[e >> 1] = im; }
+                }
+                if (lane0) { xki[0] = 0.0; xmi[0] = 0.0; }                     // X[0], X[N] of a real frame are real: keep the real parts
+            }
+            __syncthreads();                                                   // every wavefront has read phPrev / sum / inc of this round
+            // the last live wavefront of the round leaves the next round's "previous frame" and accumulator
+            const int lastLive = min(NWV - 1, A.nFrames - 1 - rd * NWV);
+            if (live && wv == lastLive) {
+#pragma unroll
+                for (int e = 0; e < 9; e++) {
+                    if (e == 8 && !lane0) continue;
+                    pv.phPrev[kb[e]] = pv.phPrev[(wv + 1) * nb + kb[e]];
+                    pv.sum[kb[e]] = ph[e] - VP_TWO_PI * rint(ph[e] * (1.0 / VP_TWO_PI));
+                }
+            }
+        }
+        lds_f2 *slot = (lds_f2 *)(slots + wv * 2048);
+        if (live) {
+            // ---- merge (the inverse of the split), scaled by c = overlap-add normalisation / N, and conjugated for the inverse transform
+            const double hc = 0.5 * A.c;
+            double zmr[4], zmi[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double s2r = xkr[q] + xmr[q], s2i = xki[q] - xmi[q];     // X[k] + conj X[N - k] = 2 E
+                const double d2r = xkr[q] - xmr[q], d2i = xki[q] + xmi[q];     // X[k] - conj X[N - k] = 2 W^k O
+                const double vr = __builtin_fma(d2r, ws[q].x, d2i * ws[q].y), vi = __builtin_fma(d2i, ws[q].x, -(d2r * ws[q].y));   // conj(W^k) (.)
+                z.re[q] = hc * (s2r - vi); z.im[q] = -hc * (s2i + vr);         // conj Z'[k],      Z'[k]     = E + i O
+                zmr[q] = hc * (s2r + vi); zmi[q] = hc * (s2i - vr);            // conj Z'[N - k],  Z'[N - k] = conj(E - i O)
+            }
+            if (lane0) {
+                z.re[0] = hc * (xkr[0] + xmr[0]); z.im[0] = -hc * (xkr[0] - xmr[0]);   // conj Z'[0] = (X0 + XN)/2 - i (X0 - XN)/2
+                zmr[0] = A.c * Pr[0]; zmi[0] = A.c * Pi[0];                    // conj Z'[N/2] = conj conj X[N/2] = X[N/2]
+            }
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; q++) xb[q * 64 + lane] = d2{zmr[q], zmi[q]};
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const d2 v = xb[(3 - u) * 64 + pl]; z.re[4 + u] = v.x; z.im[4 + u] = v.y; }
+            if (lane0) {
+                z.re[4] = zmr[0]; z.im[4] = zmi[0]; z.re[5] = zmr[3]; z.im[5] = zmi[3];
+                z.re[6] = zmr[2]; z.im[6] = zmi[2]; z.re[7] = zmr[1]; z.im[7] = zmi[1];
+            }
+            fft512(z, xb, L);                                                  // y = FFT(conj Z'): x'[2n] = Re y, x'[2n + 1] = -Im y (1/N is in c)
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) slot[lane + 64 * r] = f2{(float)(z.re[r] * wa[r].x), (float)(-(z.im[r] * wa[r].y))};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) slot[lane + 64 * r] = f2{0.f, 0.f};
+        }
+        __syncthreads();
+        // ---- overlap-add: relative hop u of this round (hops rd * NWV + u) takes frames w in [u - O + 1, u] in frame order
+        {
+            const bool emit = rd >= rFirst;
+            float *o = A.out + (size_t)s * T;
+            for (int i = tid; i < hop; i += 64 * NWV) {
+                for (int u = 0; u < NWV + O - 1; u++) {
+                    float v = (u < O - 1) ? carry[u * hop + i] : 0.f;
+                    const int wlo = max(0, u - O + 1), whi = min(u, NWV - 1);
+                    for (int w = wlo; w <= whi; w++) v += slots[w * 2048 + (u - w) * hop + i];
+                    if (u < NWV) {
+                        const long t = (long)(rd * NWV + u) * hop + i;
+                        if (emit && t < T) o[t] = v;
+                    } else carry[(u - NWV) * hop + i] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)vp_k_stft_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr = true;
+    }
+    const size_t lds = vp_stft_lds_bytes(a.F, a.hop);
+    if (a.pv)
+        hipLaunchKernelGGL(vp_k_stft_fused<true>, dim3(nRuns, nStreams), dim3(64 * NWV), lds + stft_pv_lds_bytes(a.F), st, a);
+    else
+        hipLaunchKernelGGL(vp_k_stft_fused<false>, dim3(nRuns, nStreams), dim3(64 * NWV), lds, st, a);
+    return hipGetLastError();
+}

@@ -118,6 +118,9 @@ def load_library():
     L.vp_stft_destroy.argtypes = [vp]
     L.vp_stft_num_frames.argtypes = [vp]
     L.vp_stft_roundtrip.argtypes = [vp, fp, fp, fp, C.c_void_p]
+    L.vp_stft_pitch_shift.argtypes = [vp, fp, fp, C.c_double, C.c_void_p]
+    L.vp_stft_is_fused.argtypes = [vp]
+    L.vp_stft_set_runs.argtypes = [vp, C.c_int]
     L.vp_error_string.argtypes = [C.c_int]
     L.vp_error_string.restype = C.c_char_p
     L.vp_last_error.argtypes = [vp]
@@ -412,6 +415,28 @@ class StftRoundTrip:
             stream = torch.cuda.current_stream(d_in.device).cuda_stream
         rc = self.L.vp_stft_roundtrip(self.h, d_in.data_ptr(), d_out.data_ptr(), d_mag.data_ptr() if d_mag is not None else None,
                                       C.c_void_p(stream))
+        if rc:
+            raise VpError(rc, self.L.vp_error_string(rc).decode())
+
+    @property
+    def fused(self):
+        """True when the handle runs the fused kernel (csrc/vp_stft.hip: 1024-point frames)."""
+        return self.L.vp_stft_is_fused(self.h) == 1
+
+    def set_runs(self, runs_per_stream):
+        """Diagnostic: runs of frames (workgroups) per stream, 0 = automatic; the output does not depend on it."""
+        rc = self.L.vp_stft_set_runs(self.h, int(runs_per_stream))
+        if rc:
+            raise VpError(rc, self.L.vp_error_string(rc).decode())
+
+    def pitch_shift(self, d_in, d_out, semitones, stream=None):
+        """Round trip with the phase-vocoder stage (per-bin phase unwrap / accumulate) shifting the pitch by `semitones`."""
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and tuple(d_in.shape) == (self.S, self.T) and d_in.is_contiguous()
+        assert d_out.is_cuda and tuple(d_out.shape) == (self.S, self.T) and d_out.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        rc = self.L.vp_stft_pitch_shift(self.h, d_in.data_ptr(), d_out.data_ptr(), float(semitones), C.c_void_p(stream))
         if rc:
             raise VpError(rc, self.L.vp_error_string(rc).decode())
 
