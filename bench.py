@@ -211,9 +211,17 @@ def parity_vs_oracle(make, S_, N_, fs_, prepare, params, mono_, first_stream, ii
     return out
 
 
-def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
-    """Standalone STFT->iSTFT kernel (Hann, radix-2 FFT, iFFT, OLA): NO reference counterpart, reported apart
-    from the metric."""
+# fp64 vector instructions one wavefront executes per frame in vp_k_stft_fused<false, false> (its loop body is straight-line: one pass
+# per frame), counted in the disassembly of the built library by tools/kernel_resources.py fp64_op_counts();
+# tests/test_kernel_resources.py fails when the build and these figures part.
+STFT_FP64_OPS_PER_FRAME = {"v_add_f64": 378, "v_mul_f64": 163, "v_fmac_f64": 72}
+FP64_VECTOR_PEAK_TFLOPS = 78.6                                          # MI355X: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 (FMA) x 2.4 GHz
+
+
+def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30):
+    """Standalone fused STFT->iSTFT kernel (Hann, FFT, iFFT, OLA in one launch; csrc/vp_stft.hip): NO reference counterpart, reported
+    apart from the metric, with its own roofline: HBM on the algorithmic 2048 B per frame (every input
+    sample in once, every output sample out once) and the fp64 vector share."""
     import torch
     from vocoderproject_amd import StftRoundTrip
     st = StftRoundTrip(S, T, F, hop, device=dev.index or 0)
@@ -228,8 +236,33 @@ def stft_figure(dev, S, T=1024 * 16, F=1024, hop=256, reps=20):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
     frames = S * st.n_frames
-    return {"frames_per_s": frames / dt, "note": "standalone STFT round trip 1024/256, fp64 radix-2 FFT in LDS; no reference counterpart",
-            "hbm_gbs": (2 * S * T * 4 + 2 * frames * F * 4) / dt / 1e9}
+    fps = frames / dt
+    alg = 2 * hop * 4                                                   # bytes per frame: hop samples in, hop samples out, f32
+    n = STFT_FP64_OPS_PER_FRAME
+    insts = sum(n.values())
+    flops = (n["v_add_f64"] + n["v_mul_f64"] + 2 * n["v_fmac_f64"]) * 64
+    out = {"frames_per_s": fps, "kernel": "vp_k_stft_fused<false, false>" if st.fused else "vp_k_stft_frames + vp_k_stft_ola",
+           "workload": f"{S} streams x {T} samples, {F}-pt frames hop {hop}, {st.n_frames} frames per stream, one launch per call",
+           "us_per_call": dt * 1e6,
+           "note": "standalone fused STFT round trip (sqrt-Hann, 512-pt complex register FFT per wavefront, iFFT, overlap-add in LDS); fp64; no reference counterpart",
+           "roofline": {"bound": "hbm", "achieved": fps * alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps * alg / 1e9 / HBM_PEAK_GBS,
+                        "alg_bytes_per_frame": alg, "traffic": None},
+           "fp64_valu": {"insts_per_frame_per_lane": insts, "flop_per_frame": flops, "tflops": fps * flops / 1e12,
+                         "frac_of_peak_flops": fps * flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "frac_of_issue_slots": fps * insts * 64 / VALU_LANE_OPS_PEAK,
+                         "what": "fp64 vector instructions per frame counted in the kernel's ISA (straight-line loop body) x frames/s, against "
+                                 "78.6 TFLOP/s (FMA = 2) and against the fp64 issue slots (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz)"}}
+    # the phase-vocoder stage between the transforms (vp_stft_pitch_shift, +7 semitones): one workgroup per stream
+    if st.fused:
+        for _ in range(2):
+            st.pitch_shift(x, y, 7.0)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(max(4, reps // 4)):
+            st.pitch_shift(x, y, 7.0)
+        torch.cuda.synchronize(dev)
+        out["phase_vocoder_frames_per_s"] = frames / ((time.perf_counter() - t0) / max(4, reps // 4))
+    return out
 
 
 def count_gpus_without_hip():

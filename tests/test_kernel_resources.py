@@ -18,6 +18,7 @@ BASELINE_KERNELS = [
     "vp_k_v2_fir2<40, 8, true>", "vp_k_v2_fir2<40, 8, false>", "vp_k_v2_energy_slices", "vp_k_v2_iir_fast<3, 1>", "vp_k_v2_ola",    # configs[3]
     "vp_k_pitch_fast", "vp_k_v2_levinson2<48, 32, true>", "vp_k_v2_fir2<48, 32, true>",                      # configs[4] geometry
     "vp_k_pitch_fast_multi_c", "vp_k_emit", "vp_k_ingest_gate",
+    "vp_k_stft_fused<false, false>", "vp_k_stft_fused<true, false>",                                          # the standalone STFT figures
 ]
 
 
@@ -48,3 +49,15 @@ def test_occupancy_two_for_the_full_register_builds(resources):
         assert r["vgpr"] + r["agpr"] <= 256, (k, r)
     for k in ("vp_k_pitch_lite_fast_c", "vp_k_vocoder_lite"):
         assert resources[k]["vgpr"] + resources[k]["agpr"] <= 128, (k, resources[k])
+
+
+def test_stft_kernel_fp64_instruction_count_matches_bench(resources):
+    """bench.py prices the fused STFT kernel's fp64 vector share from a count of its ISA; the count must be the built kernel's."""
+    import kernel_resources
+    from vocoderproject_amd import build
+    sys.path.insert(0, ROOT)
+    import bench
+    got = kernel_resources.fp64_op_counts(build.build(), "vp_k_stft_fused<false, false>")
+    assert got == bench.STFT_FP64_OPS_PER_FRAME, got
+    r = resources["vp_k_stft_fused<false, false>"]
+    assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] == 0        # two wavefronts per SIMD (two workgroups per CU)

@@ -48,6 +48,32 @@ def kernel_resources(lib):
     return res
 
 
+def fp64_op_counts(lib, kernel):
+    """{opcode family: static count} of the fp64 vector arithmetic in `kernel` (demangled name as kernel_resources() prints it),
+    from a disassembly of the code object in `lib`.  For a kernel whose loop body is straight-line (vp_k_stft_fused<false, false>:
+    one pass per frame) this is what a wavefront executes per pass."""
+    filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
+    with tempfile.TemporaryDirectory(prefix="vp_co_") as tmp:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, so)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            for m in re.finditer(r"^[0-9a-f]+ <(\S+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
+                dn = subprocess.run([filt, m.group(1)], capture_output=True, text=True).stdout.strip() if filt else m.group(1)
+                short = re.sub(r"\(.*", "", dn.replace("void ", "")).strip()
+                if short != kernel:
+                    continue
+                ops = re.findall(r"\b(v_(?:add|mul|fma|fmac|max|min)_f64)", m.group(2))
+                out = {}
+                for o in ops:
+                    out[o] = out.get(o, 0) + 1
+                return out
+    return None
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     lib = args[0] if args else os.path.join(ROOT, "vocoderproject_amd", "libvp_amd.so")

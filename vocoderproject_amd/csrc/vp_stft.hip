@@ -166,7 +166,8 @@ struct PvLds {
     lds_f64 *sum;              // [nb]           synthesis phase accumulator after the previous round
 };
 
-template <bool PV>
+// PV: phase-vocoder stage between the transforms; MAG: magnitude dump (builds of their own: the timed round trip carries neither)
+template <bool PV, bool MAG>
 __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
 {
     extern __shared__ double smem[];
@@ -218,19 +219,16 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
         double xkr[4], xki[4], xmr[4], xmi[4];                                 // X[k], X[N - k] of the lane's pairs
         if (live) {
             const float *x = xs + (size_t)f * hop;
+            f2 xv[8];
             if (A.aligned) {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const f2 v = *(const f2 *)(x + 2 * (lane + 64 * r));
-                    z.re[r] = (double)v.x * wa[r].x; z.im[r] = (double)v.y * wa[r].y;
-                }
+                for (int r = 0; r < 8; r++) xv[r] = *(const f2 *)(x + 2 * (lane + 64 * r));
             } else {
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const float v0 = x[2 * (lane + 64 * r)], v1 = x[2 * (lane + 64 * r) + 1];
-                    z.re[r] = (double)v0 * wa[r].x; z.im[r] = (double)v1 * wa[r].y;
-                }
+                for (int r = 0; r < 8; r++) xv[r] = f2{x[2 * (lane + 64 * r)], x[2 * (lane + 64 * r) + 1]};
             }
+#pragma unroll
+            for (int r = 0; r < 8; r++) { z.re[r] = (double)xv[r].x * wa[r].x; z.im[r] = (double)xv[r].y * wa[r].y; }
             fft512(z, xb, L);
             // ---- split: lane j owns the pairs (k, N - k), k = 64 q + j, q < 4; the partners sit in lane 64 - j's registers 7 - q
             wave_sync();
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                 xmr[0] = z.re[0] - z.im[0]; xmi[0] = 0.0;                      // X[N]   (kept in the pair's mirror slot; X[N/2] in Pr/Pi[0])
                 Pi[0] = -Pi[0];                                                // X[N/2] = conj Z[N/2]
             }
-            if (A.mag) {                                                       // |X[k]|, k <= N, natural order
+            if (MAG) {                                                         // |X[k]|, k <= N, natural order
                 float *m = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -400,13 +398,16 @@ hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStrea
 {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)vp_k_stft_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute((const void *)vp_k_stft_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr = true;
     }
     const size_t lds = vp_stft_lds_bytes(a.F, a.hop);
+    const dim3 grid(nRuns, nStreams), block(64 * NWV);
     if (a.pv)
-        hipLaunchKernelGGL(vp_k_stft_fused<true>, dim3(nRuns, nStreams), dim3(64 * NWV), lds + stft_pv_lds_bytes(a.F), st, a);
+        hipLaunchKernelGGL((vp_k_stft_fused<true, false>), grid, block, lds + stft_pv_lds_bytes(a.F), st, a);
+    else if (a.mag)
+        hipLaunchKernelGGL((vp_k_stft_fused<false, true>), grid, block, lds, st, a);
     else
-        hipLaunchKernelGGL(vp_k_stft_fused<false>, dim3(nRuns, nStreams), dim3(64 * NWV), lds, st, a);
+        hipLaunchKernelGGL((vp_k_stft_fused<false, false>), grid, block, lds, st, a);
     return hipGetLastError();
 }
