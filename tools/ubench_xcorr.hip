@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512) void k(double *out, const double *in, int F, i
             }
             tot += accA + accB;
         }
-        if (V == 1 || V == 2) {
+        if (V == 1 || V == 2 || V == 4) {
             const int nl = (tauMax + 7) >> 3;
             const int l = min(lane, nl - 1);
             const int q = wv - 1, i0 = q * (F >> 2), i1 = i0 + (F >> 2);
@@ -94,6 +94,28 @@ __global__ __launch_bounds__(512) void k(double *out, const double *in, int F, i
                     if (i + 32 < i1) { NLOAD(v0, i + 32) En = xa[i + 32 + l16]; }
                     COMP8(v1)
                     E = En;
+                }
+            } else if (V == 4) {
+                // uniform factor through v_readlane into scalar registers (one LDS read per 16 elements), eight plain fused multiply-adds per element
+                double ev = xa[i0 + l16], evn = 0.0;
+                for (int i = i0; i < i1; i += 16) {
+                    double w[24];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { w[2 * u] = c[u].x; w[2 * u + 1] = c[u].y; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { w[8 + 2 * u] = v0[u].x; w[9 + 2 * u] = v0[u].y; }
+                    if (i + 16 < i1) { NLOAD(v1, i + 16) evn = xa[i + 16 + l16]; }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const double eu = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ev), u), __builtin_amdgcn_readlane(__double2loint(ev), u));
+                        a0 = __builtin_fma(eu, w[u], a0); a1 = __builtin_fma(eu, w[u + 1], a1); a2 = __builtin_fma(eu, w[u + 2], a2);
+                        a3 = __builtin_fma(eu, w[u + 3], a3); a4 = __builtin_fma(eu, w[u + 4], a4); a5 = __builtin_fma(eu, w[u + 5], a5);
+                        a6 = __builtin_fma(eu, w[u + 6], a6); a7 = __builtin_fma(eu, w[u + 7], a7);
+                    }
+                    c[0] = v0[4]; c[1] = v0[5]; c[2] = v0[6]; c[3] = v0[7];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v0[u] = v1[u];
+                    ev = evn;
                 }
             } else {
                 // uniform factor as an LDS broadcast read, eight plain fused multiply-adds per element
@@ -183,5 +205,6 @@ int main()
     run<1>("V1 eight lags per lane, a quarter of the elements per wave, DPP");
     run<2>("V2 eight lags per lane, quarter, LDS broadcast + plain fma");
     run<3>("V3 four lags per lane, two waves per half, DPP");
+    run<4>("V4 eight lags per lane, quarter, v_readlane -> SGPR factor + plain fma");
     return 0;
 }
