@@ -127,17 +127,20 @@ extern "C" const char *vp_last_error(const vp_handle *h) { return h ? h->lastErr
 
 // large batches: the register-light build lets two workgroups share a CU (needs <= 80 KB LDS each and no big
 // register-resident exact-IIR instantiation)
-static bool pitch_lite(const vp_handle *h, bool iirFast, bool yinFft)
+static bool pitch_lite(const vp_handle *h, bool iirFast)
 {
     // (htabGlobal: the register-light builds are compiled for the global Hann table only; prepare sets it for exactly these batches)
-    return h->g.S > 256 && !yinFft && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024 && h->g.htabGlobal;
+    return h->g.S > 256 && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024 && h->g.htabGlobal;
 }
 
 // geometry and order for which the common-case builds (vp_k_pitch*_c) are valid
 static bool pitch_common(const vp_handle *h)
 {
     // (the last term: room behind the YIN window's prefix sums in eFrame for the quarter sums of xcorr8_quarter, vp_pitch.inc xc8_ok)
-    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512 && h->g.eLen >= h->g.F + 4 * h->g.tauMax + 1;
+    // (round 4: frames of one or two whole 512-sample segments -- 22.05 and 44.1 kHz with the plugin's geometry -- and room for the FFT
+    // cross-correlation's tables and exchange buffers: the full-register common-case builds carry no other form of the certified YIN)
+    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512 && h->g.eLen >= h->g.F + 4 * h->g.tauMax + 1 &&
+           (h->g.F == 512 || h->g.F == 1024) && h->pitchLds + 16 + vp_pitch_fft_lds_bytes(2 * (h->g.F >> 9)) <= h->ldsMax;
 }
 
 // geometry and modes for which the analysis front end of multi-block launches (vp_k_pitch_front) can stand in for the serial kernel's
@@ -153,11 +156,10 @@ static bool pitch_front_ok(const vp_handle *h)
 typedef void (*vp_dsp_kernel)(VpGeom, VpCall, VpDev, const float *, float *);
 struct PitchPlan { vp_dsp_kernel fn; const char *name; size_t lds; };
 #define VP_PLAN(K, LDS) PitchPlan{K, #K, LDS}
-static PitchPlan pitch_plan(const vp_handle *h, bool fast, bool fft, int nBlocks)
+static PitchPlan pitch_plan(const vp_handle *h, bool fast, int nBlocks)
 {
-    const bool lite = pitch_lite(h, fast, fft), com = pitch_common(h);
+    const bool lite = pitch_lite(h, fast), com = pitch_common(h);
     const size_t lds = h->pitchLds;
-    if (fft) return fast ? VP_PLAN(vp_k_pitch_fast_fft, lds + vp_pitch_fft_lds_bytes(h->g)) : VP_PLAN(vp_k_pitch_fft, lds + vp_pitch_fft_lds_bytes(h->g));   // never `lite` (pitch_lite)
     if (nBlocks > 1) {                                    // (`lite` multi-block launches exist for the FAST recursion only: process_blocks_device)
         if (lite) return com ? VP_PLAN(vp_k_pitch_lite_fast_multi_c, lds) : VP_PLAN(vp_k_pitch_lite_fast_multi, lds);
         return fast ? (com ? VP_PLAN(vp_k_pitch_fast_multi_c, lds) : VP_PLAN(vp_k_pitch_fast_multi, lds)) : VP_PLAN(vp_k_pitch_multi, lds);
@@ -166,12 +168,20 @@ static PitchPlan pitch_plan(const vp_handle *h, bool fast, bool fft, int nBlocks
     if (com) return fast ? VP_PLAN(vp_k_pitch_fast_c, lds) : VP_PLAN(vp_k_pitch_c, lds);
     return fast ? VP_PLAN(vp_k_pitch_fast, lds) : VP_PLAN(vp_k_pitch, lds);
 }
+// The certified cross-correlation YIN of the full-register common-case builds (vp_k_pitch_c, vp_k_pitch_fast_c, vp_k_pitch_fast_multi_c)
+// evaluates its cross-correlations by FFT (vp_pitch.inc xcorr_fft_wave; they carry no other form): one wavefront per forward transform,
+// two per 512-sample segment of the frame.  0: the launch does not use it.
+static int pitch_xfft_waves(const vp_handle *h, bool fast, int nBlocks)
+{
+    if (!pitch_common(h) || pitch_lite(h, fast) || (nBlocks > 1 && !fast)) return 0;
+    return 2 * (h->g.F >> 9);
+}
 #undef VP_PLAN
 
 extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
-    return pitch_plan(h, h->iirMode == VP_IIR_FAST, h->yinMode == VP_YIN_FFT && h->g.fftLog > 0, 1).name;
+    return pitch_plan(h, h->iirMode == VP_IIR_FAST, 1).name;
 }
 
 // vp_k_vocoder_lite (FAST IIR only, <= 128 VGPRs): above 256 streams, with at most four window slots so that two
@@ -594,15 +604,6 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     }
     h->pitchLds = vp_pitch_lds_bytes(g);
     h->ldsMax = ldsMax;
-    // FFT accelerator: smallest power of two >= F + tauMax, if its work arrays still fit
-    g.fftLog = 0;
-    {
-        int lg = 1;
-        while ((1 << lg) < F + g.tauMax) lg++;
-        VpGeom t = g;
-        t.fftLog = lg;
-        if (h->pitchLds + vp_pitch_fft_lds_bytes(t) <= ldsMax && (1 << lg) <= 2 * F) g.fftLog = lg;   // |Ff|^2 borrows outEFrame+yFrame
-    }
     if (h->pitchLds > ldsMax) { h->lastError = "pitch frame does not fit LDS"; return VP_ERR_GEOMETRY; }
     int nw = 8;
     while (nw > 1 && vp_voc_lds_bytes(W, nw) > ldsMax) nw--;
@@ -615,7 +616,6 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     {
         const void *fns[] = {(const void *)vp_k_pitch, (const void *)vp_k_pitch_fast, (const void *)vp_k_pitch_multi,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
-                             (const void *)vp_k_pitch_fft, (const void *)vp_k_pitch_fast_fft,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
                              (const void *)vp_k_pitch_front, (const void *)vp_k_pitch_front_fast,
@@ -651,15 +651,23 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_upload(h, &d.hannOff, hannOff));
     RC(dev_upload(h, &d.notes, notes));
     RC(dev_upload(h, &d.notesN, notesN));
-    if (g.fftLog) {
-        const int M = 1 << g.fftLog;
-        std::vector<double> twr(M / 2), twi(M / 2);
-        for (int j = 0; j < M / 2; j++) {
-            const double ang = -2.0 * 3.141592653589793238 * (double)j / (double)M;
-            twr[j] = std::cos(ang); twi[j] = std::sin(ang);
+    {   // per-lane twiddles of the wavefront FFT (vp_fft.inc fft512) and of the real-input split, host libm
+        const double PI = 3.141592653589793238;
+        std::vector<double> t1(64 * 8 * 2), t2(64 * 8 * 2), ts(64 * 4 * 2);
+        for (int lane = 0; lane < 64; lane++) {
+            for (int r = 0; r < 8; r++) {
+                const double a1 = -2.0 * PI * (double)(r * (lane >> 3)) / 64.0, a2 = -2.0 * PI * (double)(r * lane) / 512.0;
+                t1[(lane * 8 + r) * 2] = std::cos(a1); t1[(lane * 8 + r) * 2 + 1] = std::sin(a1);
+                t2[(lane * 8 + r) * 2] = std::cos(a2); t2[(lane * 8 + r) * 2 + 1] = std::sin(a2);
+            }
+            for (int q = 0; q < 4; q++) {
+                const double a = -2.0 * PI * (double)(64 * q + lane) / 1024.0;
+                ts[(lane * 4 + q) * 2] = std::cos(a); ts[(lane * 4 + q) * 2 + 1] = std::sin(a);
+            }
         }
-        RC(dev_upload(h, &d.twRe, twr));
-        RC(dev_upload(h, &d.twIm, twi));
+        RC(dev_upload(h, &d.fftTw1, t1));
+        RC(dev_upload(h, &d.fftTw2, t2));
+        RC(dev_upload(h, &d.fftTws, ts));
     }
     RC(dev_alloc(h, &h->dMapAll, (size_t)S));
     {   // scratch of the batched vocoder pipeline (a block has at most ceil(N / hop) windows per stream)
@@ -851,8 +859,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
         c0.inMono = 0;
         h->synthNonZero = g.inSize;
     }
-    c0.yinFft = (h->yinMode == VP_YIN_FFT && g.fftLog > 0) ? 1 : 0;
-    c0.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
+    c0.yinCert = (h->yinMode == VP_YIN_XCORR || h->yinMode == VP_YIN_FFT) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
 
     for (auto &co : h->cohorts) {
         VpCall c = c0;
@@ -896,7 +903,11 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                     if ((f->err = hipEventRecord(h->evFork, f->st)) != hipSuccess) return;
                     if ((f->err = hipStreamWaitEvent(h->auxStream, h->evFork, 0)) != hipSuccess) return;
                     ProfScope ps(h, h->auxStream, 2);
-                    const PitchPlan plan = pitch_plan(h, true, f->cp.yinFft != 0, 1);
+                    PitchPlan plan = pitch_plan(h, true, 1);
+                    if (const int fw = f->cp.yinCert ? pitch_xfft_waves(h, true, 1) : 0) {
+                        const size_t off = (plan.lds + 15) / 16 * 16;
+                        f->cp.fftOff = (int)off; f->cp.fftWaves = fw; plan.lds = off + vp_pitch_fft_lds_bytes(fw);
+                    }
                     f->cp.ldsBytes = (int)plan.lds;
                     hipLaunchKernelGGL(plan.fn, dim3(f->n), dim3(512), plan.lds, h->auxStream, f->g, f->cp, f->dp, f->in, f->out);
                 };
@@ -944,8 +955,8 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cp.fuseIngest = runVoc ? 0 : 1; cp.fuseEmit = 1;
                 cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
                 ProfScope ps(h, st, 2);
-                PitchPlan plan = pitch_plan(h, cp.iirFast != 0, cp.yinFft != 0, nBlocks);
-                if (nBlocks > 1 && !cp.yinFft && pitch_front_ok(h)) {
+                PitchPlan plan = pitch_plan(h, cp.iirFast != 0, nBlocks);
+                if (nBlocks > 1 && pitch_front_ok(h)) {
                     // yin() and the LPC of every frame that starts inside the launch, one workgroup per (stream, frame),
                     // ahead of the serial kernel.  The frame starts follow from the counters (PitchProcess.cpp:166-196).
                     VpFront fr;
@@ -965,16 +976,26 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                     }
                     if (fits && fr.nFr > 0) {
                         VpCall cf = cp;
-                        cf.ldsBytes = (int)vp_pitch_front_lds_bytes(g);
-                        hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_front_fast : vp_k_pitch_front, dim3(co.n, fr.nFr), dim3(512), vp_pitch_front_lds_bytes(g), st,
+                        const size_t fl = vp_pitch_front_lds_bytes(g);
+                        cf.fftOff = 0; cf.fftWaves = 0;                    // (the front end keeps the fused-multiply-add form: 128 registers)
+                        cf.ldsBytes = (int)fl;
+                        hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_front_fast : vp_k_pitch_front, dim3(co.n, fr.nFr), dim3(512), fl, st,
                                            g, cf, d, fr, d_in);
                         cp.front = 1;
                     }
                 }
                 // one workgroup per CU anyway (S <= 256 or a frame beyond half a CU's LDS): the block's accumulator slice rides in LDS
-                if (nBlocks == 1 && !cp.yinFft && !pitch_lite(h, cp.iirFast != 0, false) && plan.lds + vp_pitch_acc_lds_bytes(g) + 16 <= h->ldsMax) {
+                // the block's accumulator slice in LDS when it fits beside the FFT cross-correlation's minimum (tables + one buffer)
+                const int fw = cp.yinCert ? pitch_xfft_waves(h, cp.iirFast != 0, nBlocks) : 0;
+                const size_t fftMin = fw ? vp_pitch_fft_lds_bytes(fw) + 16 : 0;
+                if (nBlocks == 1 && !pitch_lite(h, cp.iirFast != 0) && plan.lds + vp_pitch_acc_lds_bytes(g) + 16 + fftMin <= h->ldsMax) {
                     cp.ldsAcc = 1;
                     plan.lds = ((plan.lds + 15) / 16) * 16 + vp_pitch_acc_lds_bytes(g);
+                }
+                // certified YIN of the full-register common-case builds: tables and exchange buffers behind everything else
+                if (fw) {
+                    const size_t off = (plan.lds + 15) / 16 * 16;
+                    cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + vp_pitch_fft_lds_bytes(fw);
                 }
                 cp.ldsBytes = (int)plan.lds;
                 hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
@@ -1153,7 +1174,6 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     if (!co.vocOn || !co.pitchOn || !voc_pipeline_wanted(h)) return VP_OK;
     if (co.oVmax > V2_ORDER_MAX || co.oSmax > VP_ORDER_MAX_SYNTH || co.oVmax < 2 || co.oSmax < 2) return VP_OK;
     if ((size_t)g.outSize * sizeof(double) > (size_t)VP_V2_MB_LDS_MAX) return VP_OK;
-    if (h->yinMode == VP_YIN_FFT && g.fftLog > 0) return VP_OK;
     VpV2MB mb;
     memset(&mb, 0, sizeof mb);
     mb.nBlocks = nb; mb.preIngested = 1;
@@ -1177,7 +1197,7 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     memset(&c, 0, sizeof c);
     c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
     c.iirFast = 1; c.nBlocks = nb; c.inMono = 0; c.vocOn = 1; c.pitchOn = 1;
-    c.yinCert = (h->yinMode == VP_YIN_XCORR) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
+    c.yinCert = (h->yinMode == VP_YIN_XCORR || h->yinMode == VP_YIN_FFT) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
     VpDev d = h->d;
     d.streamMap = co.dMap;
     d.gateB = h->gateB;
@@ -1191,7 +1211,11 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
         cp.fuseIngest = 1; cp.fuseEmit = 0; cp.pitchLin = 1;
         VpDev dp = d;
         dp.outAcc = h->pLin; dp.outAcc2 = nullptr;
-        const PitchPlan plan = pitch_plan(h, true, false, nb);
+        PitchPlan plan = pitch_plan(h, true, nb);
+        if (const int fw = cp.yinCert ? pitch_xfft_waves(h, true, nb) : 0) {
+            const size_t off = (plan.lds + 15) / 16 * 16;
+            cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + vp_pitch_fft_lds_bytes(fw);
+        }
         cp.ldsBytes = (int)plan.lds;
         ProfScope ps(h, st, 2);
         hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, gp, cp, dp, d_in, d_out);
@@ -1238,11 +1262,11 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     if (h->poisoned) return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, 1, mono);       // reports it
     int rc = sync_stream_state(h, (hipStream_t)hip_stream);                   // the plan below depends on the cohorts
     if (rc) { h->poisoned = true; return rc; }
-    const bool fast = h->iirMode == VP_IIR_FAST, fft = h->yinMode == VP_YIN_FFT && h->g.fftLog > 0;
+    const bool fast = h->iirMode == VP_IIR_FAST;
     const bool pitchOnly = h->cohorts.size() == 1 && h->cohorts[0].pitchOn && !h->cohorts[0].vocOn;
     // one launch of the serial kernel for all the blocks (state stays on chip between them), behind the time-parallel analysis
     // front end where the geometry allows it; above 256 streams the register-light builds exist for the FAST recursion only
-    if (pitchOnly && n_blocks > 1 && !fft && (!pitch_lite(h, fast, fft) || fast))
+    if (pitchOnly && n_blocks > 1 && (!pitch_lite(h, fast) || fast))
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
     const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
     if (!mono && n_blocks > 1) {                               // vocoder-only plan on the batched pipeline: groups of blocks per launch
@@ -1508,7 +1532,6 @@ extern "C" int vp_get_iir_mode(const vp_handle *h) { return h ? h->iirMode : VP_
 extern "C" int vp_set_yin_mode(vp_handle *h, int mode)
 {
     if (!h || mode < VP_YIN_DIRECT || mode > VP_YIN_XCORR_FORCE_FALLBACK) return VP_ERR_INVALID_ARG;
-    if (mode == VP_YIN_FFT && h->prepared && h->g.fftLog == 0) return VP_ERR_GEOMETRY;    // work arrays do not fit LDS
     h->yinMode = mode;
     return VP_OK;
 }

@@ -28,7 +28,6 @@ struct VpGeom {
     int orderPitch;      // lpcPitch as read at prepare (PitchProcess.cpp:70)
     int tau0;            // floor(fS/fMax) (PitchProcess.cpp:429)
     int bufferIdxMax;    // latency + N (PitchProcess.cpp:138)
-    int fftLog;          // log2 of the FFT size of the VP_YIN_FFT accelerator (>= F + tauMax points), 0 = unavailable
     int xsSteps;         // chunk steps whose voice window is staged in LDS at once (pitch kernel)
     int htabGlobal;      // pitch kernel: the frame's Hann(2T+1) window is read from the global table instead of an LDS copy (batches of
                          // more than 256 streams: the 7 KB buy the staging of the block's later chunk steps within half a CU's LDS)
@@ -44,7 +43,9 @@ struct VpCall {
     int pStart, nChunk0, nSteps; // pitch chunk steps start at pStart + j*C
     int pitchOn, vocOn, inplace;
     int fuseIngest, fuseEmit;    // this launch also runs the ingest+gate prologue / the emit epilogue
-    int yinFft;                  // 1: FFT accelerator for the YIN difference function + LPC autocorrelation
+    int fftOff, fftWaves;        // VP_YIN_FFT: byte offset, in the launch's dynamic LDS, of [64-byte flag block | fftWaves x 8 KB exchange buffers]
+                                 // for the certified form's cross-correlations by FFT (xcorr_fft_wave), 0 = the fused-multiply-add form;
+                                 // wavefronts 1..fftWaves of the workgroup transform
     int yinCert;                 // 1: cross-correlation form of the difference function (fused multiply-adds)
     int iirFast;                 // 0: exact (reference summation order), 1: transposed-form fast IIR
     int ldsBytes;                // dynamic LDS of this launch (used by the -DVP_POISON_LDS diagnostic build only)
@@ -86,6 +87,7 @@ struct VpPitchState {
 // Time-parallel analysis front end (vp_k_pitch_front): what PitchProcess::processChunkStart computes from the INPUT
 // alone (PitchProcess.cpp:203-233: yin() and the frame's LPC), for every frame that starts inside a multi-block launch, one
 // workgroup per (stream, frame); the serial kernel then only places marks and synthesises.
+#define VP_FFT_TW_D2 (64 + 512 + 256)   // complex doubles of the wavefront FFT's twiddle tables (vp_fft.inc)
 #define VP_FRONT_MAX 32              // frame starts per launch and stream the record array holds
 struct VpFrontRec {
     double pitch;                    // yin(): fs / period, 0 = unvoiced (PitchProcess.cpp:411-448)
@@ -113,7 +115,7 @@ struct VpDev {
     const int *hannOff;      // [tauMax+1]
     const double *notes;     // [13][VP_NOTES_STRIDE]
     const int *notesN;       // [13]
-    const double *twRe, *twIm; // [M/2] exp(-2 pi i j / M)
+    const double *fftTw1, *fftTw2, *fftTws;   // per-lane twiddles of the wavefront FFT (vp_fft.inc): [64][8][2], [64][8][2], [64][4][2]
     unsigned long long *ub;  // [5]
     unsigned long long *dbg; // [64] phase timers of the -DVP_STAMPS diagnostic build
     double *outAcc2;         // [S][outSize] second accumulator, non-null in the emit stage while it may hold anything: in

@@ -18,8 +18,6 @@ __global__ void vp_k_pitch_c(VpGeom g, VpCall c, VpDev d, const float *__restric
 __global__ void vp_k_pitch_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_fast_multi_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_lite_fast_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
-__global__ void vp_k_pitch_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
-__global__ void vp_k_pitch_fast_fft(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_lite_fast_multi(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_lite_fast_multi_c(VpGeom g, VpCall c, VpDev d, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_front(VpGeom g, VpCall c, VpDev d, VpFront fr, const float *__restrict__ in);
@@ -27,8 +25,9 @@ __global__ void vp_k_pitch_front_fast(VpGeom g, VpCall c, VpDev d, VpFront fr, c
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
 
 
-// extra dynamic LDS of the VP_YIN_FFT accelerator (re/im arrays)
-static inline size_t vp_pitch_fft_lds_bytes(const VpGeom &g) { return g.fftLog ? ((size_t)3 << g.fftLog) * sizeof(double) : 0; }   // re, im, twiddles
+// extra dynamic LDS of VP_YIN_FFT (certified cross-correlations by FFT): a 64-byte flag block and an 8 KB exchange buffer per transforming wavefront
+// and the LDS copies of the twiddle tables ([8][8] + [64][8] + [64][4] complex doubles)
+static inline size_t vp_pitch_fft_lds_bytes(int waves) { return 64 + (size_t)VP_FFT_TW_D2 * 16 + (size_t)waves * 8192; }
 static inline size_t vp_voc_lds_bytes(int W, int nWaves)
 {
     return (VP_VOC_SHARED_DOUBLES(W) + (size_t)nWaves * voc_wave_doubles(W)) * sizeof(double);

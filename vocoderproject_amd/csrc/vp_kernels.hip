@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void vp_k_ingest_gate(VpGeom g, VpCall c, VpDe
 #endif
 
 // The kernels proper, in three parts (one translation unit: they share the helpers above and each other's routines):
+#include "vp_fft.inc"            // the wavefront-level FFT (512 complex points in one wavefront's registers) and the real-input split
 #include "vp_filters.inc"        // Levinson-Durbin, autocorrelation, FIR, energies, the forms of the all-pole recursion
 #include "vp_vocoder_wg.inc"     // K1: workgroup-per-stream vocoder
 #include "vp_pitch.inc"          // LDS FFT + K2: pitch corrector

@@ -41,102 +41,9 @@
 #define WAVE 64
 #define NWV VP_STFT_WAVES
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) d2 lds_d2;
-typedef __attribute__((address_space(3))) f2 lds_f2;
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) double lds_f64;
-
-// LDS operations of one wavefront execute in order; this only keeps the COMPILER from moving a lane's read of what another lane
-// wrote across that write (no instruction is emitted for a wavefront-scope fence).
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-struct C8 { double re[8], im[8]; };
-
-// 4-point DFT, natural order in and out
-#define VP_DFT4(R0, I0, R1, I1, R2, I2, R3, I3, OR0, OI0, OR1, OI1, OR2, OI2, OR3, OI3) do { \
-        const double e0r = (R0) + (R2), e0i = (I0) + (I2), e1r = (R0) - (R2), e1i = (I0) - (I2); \
-        const double f0r = (R1) + (R3), f0i = (I1) + (I3), gr = (R1) - (R3), gi = (I1) - (I3); \
-        OR0 = e0r + f0r; OI0 = e0i + f0i; OR2 = e0r - f0r; OI2 = e0i - f0i; \
-        OR1 = e1r + gi;  OI1 = e1i - gr;  OR3 = e1r - gi;  OI3 = e1i + gr; } while (0)
-
-// 8-point DFT of the lane's eight registers, natural order in and out: one radix-2 step (the odd half turned by W8^n), two DFT4s
-__device__ __forceinline__ void dft8(C8 &z)
-{
-    const double h = 0.70710678118654752440;
-    double ar[4], ai[4], br[4], bi[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        ar[t] = z.re[t] + z.re[t + 4]; ai[t] = z.im[t] + z.im[t + 4];
-        br[t] = z.re[t] - z.re[t + 4]; bi[t] = z.im[t] - z.im[t + 4];
-    }
-    const double t1r = (br[1] + bi[1]) * h, t1i = (bi[1] - br[1]) * h;          // b1 W8
-    const double t2r = bi[2], t2i = -br[2];                                      // b2 (-i)
-    const double t3r = (bi[3] - br[3]) * h, t3i = -(br[3] + bi[3]) * h;         // b3 W8^3
-    VP_DFT4(ar[0], ai[0], ar[1], ai[1], ar[2], ai[2], ar[3], ai[3], z.re[0], z.im[0], z.re[2], z.im[2], z.re[4], z.im[4], z.re[6], z.im[6]);
-    VP_DFT4(br[0], bi[0], t1r, t1i, t2r, t2i, t3r, t3i, z.re[1], z.im[1], z.re[3], z.im[3], z.re[5], z.im[5], z.re[7], z.im[7]);
-}
-
-// z[r] *= tw[r], r = 1..7 (tw[0] = 1)
-__device__ __forceinline__ void twiddle7(C8 &z, const d2 (&tw)[8])
-{
-#pragma unroll
-    for (int r = 1; r < 8; r++) {
-        const double xr = z.re[r], xi = z.im[r];
-        z.re[r] = __builtin_fma(xr, tw[r].x, -(xi * tw[r].y));
-        z.im[r] = __builtin_fma(xr, tw[r].y, xi * tw[r].x);
-    }
-}
-
-// Per-lane constants of the 512-point transform: exchange addresses (units of 16 bytes inside the wavefront's buffer) and twiddles
-struct FftLane {
-    int w1, r1, w2;            // bases of exchange 1's stores and loads, exchange 2's stores
-    int r2[8];                 // exchange 2's loads (the skew is a rotation: not affine in the register index)
-    d2 tw1[8], tw2[8];
-};
-
-__device__ __forceinline__ void fft_lane_init(FftLane &L, int lane, const double *tw1, const double *tw2)
-{
-    const int a = lane & 7, hi = lane >> 3;
-    // exchange 1: lane (a, m0 = hi) register j0 -> A1 = a + 8 (j0 & 1) + 16 (m0 + 8 (j0 >> 1)); read by lane (a, j0 = hi), register m0
-    L.w1 = a + 16 * hi;
-    L.r1 = a + 8 * (hi & 1) + 128 * (hi >> 1);
-    // exchange 2: lane (a, j0 = hi) register j1 -> B = ((a + j0) & 7) + 8 (j1 & 1) + 16 (j0 + 8 (j1 >> 1)); read by lane j = j0 + 8 j1, register a
-    L.w2 = ((a + hi) & 7) + 16 * hi;
-#pragma unroll
-    for (int r = 0; r < 8; r++) L.r2[r] = ((r + a) & 7) + 8 * (hi & 1) + 16 * (a + 8 * (hi >> 1));
-    const d2 *t1 = (const d2 *)tw1 + lane * 8, *t2 = (const d2 *)tw2 + lane * 8;
-#pragma unroll
-    for (int r = 0; r < 8; r++) { L.tw1[r] = t1[r]; L.tw2[r] = t2[r]; }
-}
-
-// 512-point complex FFT of one wavefront: natural order in (z.re[r] <-> index lane + 64 r) and out.
-//   step A: DFT8 over m1 (n = a + 8 m0 + 64 m1);  step B: twiddle W_64^(m0 j0), DFT8 over m0;  step C: twiddle W_512^(a j), DFT8 over a
-__device__ __forceinline__ void fft512(C8 &z, lds_d2 *buf, const FftLane &L)
-{
-    dft8(z);
-    wave_sync();
-#pragma unroll
-    for (int j0 = 0; j0 < 8; j0++) buf[L.w1 + 8 * (j0 & 1) + 128 * (j0 >> 1)] = d2{z.re[j0], z.im[j0]};
-    wave_sync();
-#pragma unroll
-    for (int m0 = 0; m0 < 8; m0++) { const d2 v = buf[L.r1 + 16 * m0]; z.re[m0] = v.x; z.im[m0] = v.y; }
-    twiddle7(z, L.tw1);
-    dft8(z);
-    wave_sync();
-#pragma unroll
-    for (int j1 = 0; j1 < 8; j1++) buf[L.w2 + 8 * (j1 & 1) + 128 * (j1 >> 1)] = d2{z.re[j1], z.im[j1]};
-    wave_sync();
-#pragma unroll
-    for (int a = 0; a < 8; a++) { const d2 v = buf[L.r2[a]]; z.re[a] = v.x; z.im[a] = v.y; }
-    twiddle7(z, L.tw2);
-    dft8(z);
-}
+#include "vp_fft.inc"
 
 // exchange buffers / output slots, overlap-add carry (F - hop floats), rounded up to 16 bytes
 __host__ __device__ static inline size_t stft_lds_base(int F, int hop)
@@ -197,7 +104,6 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
     for (int r = 0; r < 8; r++) wa[r] = ((const d2 *)A.win)[lane + 64 * r];
 #pragma unroll
     for (int q = 0; q < 4; q++) ws[q] = ((const d2 *)A.tws)[lane * 4 + q];
-    const int pl = (64 - lane) & 63;                                           // the lane that holds the mirror bins
     const bool lane0 = lane == 0;
 
     for (int i = tid; i < F - hop; i += 64 * NWV) carry[i] = 0.f;
@@ -215,8 +121,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
         const int f = rd * NWV + wv;
         const bool live = f < A.nFrames;                                       // (wavefront-uniform)
         C8 z;
-        double Pr[4], Pi[4];                                                   // mirror bins Z[N - k] of the lane's pairs
-        double xkr[4], xki[4], xmr[4], xmi[4];                                 // X[k], X[N - k] of the lane's pairs
+        RPairs X;                                                              // X[k], X[N - k] of the lane's pairs (vp_fft.inc)
         if (live) {
             const float *x = xs + (size_t)f * hop;
             f2 xv[8];
@@ -230,39 +135,16 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
 #pragma unroll
             for (int r = 0; r < 8; r++) { z.re[r] = (double)xv[r].x * wa[r].x; z.im[r] = (double)xv[r].y * wa[r].y; }
             fft512(z, xb, L);
-            // ---- split: lane j owns the pairs (k, N - k), k = 64 q + j, q < 4; the partners sit in lane 64 - j's registers 7 - q
-            wave_sync();
-#pragma unroll
-            for (int u = 0; u < 4; u++) xb[u * 64 + lane] = d2{z.re[4 + u], z.im[4 + u]};
-            wave_sync();
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const d2 v = xb[(3 - q) * 64 + pl]; Pr[q] = v.x; Pi[q] = v.y; }
-            if (lane0) {                                                       // lane 0's mirrors are its own: N - 64 q = 64 (8 - q); slot 0 takes k = N / 2
-                Pr[0] = z.re[4]; Pi[0] = z.im[4]; Pr[1] = z.re[7]; Pi[1] = z.im[7];
-                Pr[2] = z.re[6]; Pi[2] = z.im[6]; Pr[3] = z.re[5]; Pi[3] = z.im[5];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double e2r = z.re[q] + Pr[q], e2i = z.im[q] - Pi[q];     // Z[k] + conj Z[N - k]
-                const double dr = z.re[q] - Pr[q], di = z.im[q] + Pi[q];       // Z[k] - conj Z[N - k]
-                const double ur = __builtin_fma(dr, ws[q].x, -(di * ws[q].y)), ui = __builtin_fma(dr, ws[q].y, di * ws[q].x);   // W^k (.)
-                xkr[q] = 0.5 * (e2r + ui); xki[q] = 0.5 * (e2i - ur);          // X[k]     = E + W^k O
-                xmr[q] = 0.5 * (e2r - ui); xmi[q] = -0.5 * (e2i + ur);         // X[N - k] = conj(E - W^k O)
-            }
-            if (lane0) {                                                       // k = 0: X[0] and X[N] (both real) share Z[0]; k = N / 2: X = conj Z
-                xkr[0] = z.re[0] + z.im[0]; xki[0] = 0.0;                      // X[0]
-                xmr[0] = z.re[0] - z.im[0]; xmi[0] = 0.0;                      // X[N]   (kept in the pair's mirror slot; X[N/2] in Pr/Pi[0])
-                Pi[0] = -Pi[0];                                                // X[N/2] = conj Z[N/2]
-            }
+            rfft_split(z, xb, lane, (const d2 *)ws, X);
             if (MAG) {                                                         // |X[k]|, k <= N, natural order
                 float *m = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int k = 64 * q + lane;
-                    m[k] = (float)sqrt(xkr[q] * xkr[q] + xki[q] * xki[q]);
-                    m[N - k] = (float)sqrt(xmr[q] * xmr[q] + xmi[q] * xmi[q]);          // (lane 0, q = 0: X[N] sits in the mirror slot)
+                    m[k] = (float)sqrt(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]);
+                    m[N - k] = (float)sqrt(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]);      // (lane 0, q = 0: X[N] sits in the mirror slot)
                 }
-                if (lane0) m[N / 2] = (float)sqrt(Pr[0] * Pr[0] + Pi[0] * Pi[0]);
+                if (lane0) m[N / 2] = (float)sqrt(X.hr * X.hr + X.hi * X.hi);
             }
         }
         if (PV) {
@@ -276,10 +158,10 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     kb[2 * q] = 64 * q + lane; kb[2 * q + 1] = N - kb[2 * q];
-                    mg[2 * q] = sqrt(xkr[q] * xkr[q] + xki[q] * xki[q]); ph[2 * q] = atan2(xki[q], xkr[q]);
-                    mg[2 * q + 1] = sqrt(xmr[q] * xmr[q] + xmi[q] * xmi[q]); ph[2 * q + 1] = atan2(xmi[q], xmr[q]);
+                    mg[2 * q] = sqrt(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]); ph[2 * q] = atan2(X.ki[q], X.kr[q]);
+                    mg[2 * q + 1] = sqrt(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]); ph[2 * q + 1] = atan2(X.mi[q], X.mr[q]);
                 }
-                kb[8] = N / 2; mg[8] = sqrt(Pr[0] * Pr[0] + Pi[0] * Pi[0]); ph[8] = atan2(Pi[0], Pr[0]);      // lane 0 only
+                kb[8] = N / 2; mg[8] = sqrt(X.hr * X.hr + X.hi * X.hi); ph[8] = atan2(X.hi, X.hr);            // lane 0 only
 #pragma unroll
                 for (int e = 0; e < 9; e++) if (e < 8 || lane0) pv.phPrev[(wv + 1) * nb + kb[e]] = ph[e];
             }
@@ -320,11 +202,11 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                     double sn, cs;
                     sincos(sp, &sn, &cs);
                     const double re = mg[e] * cs, im = mg[e] * sn;
-                    if (e == 8) { Pr[0] = re; Pi[0] = im; }
-                    else if (e & 1) { xmr[e >> 1] = re; xmi[e >> 1] = im; }
-                    else { xkr[e >> 1] = re; xki[e >> 1] = im; }
+                    if (e == 8) { X.hr = re; X.hi = im; }
+                    else if (e & 1) { X.mr[e >> 1] = re; X.mi[e >> 1] = im; }
+                    else { X.kr[e >> 1] = re; X.ki[e >> 1] = im; }
                 }
-                if (lane0) { xki[0] = 0.0; xmi[0] = 0.0; }                     // X[0], X[N] of a real frame are real: keep the real parts
+                if (lane0) { X.ki[0] = 0.0; X.mi[0] = 0.0; }                   // X[0], X[N] of a real frame are real: keep the real parts
             }
             __syncthreads();                                                   // every wavefront has read phPrev / sum / inc of this round
             // the last live wavefront of the round leaves the next round's "previous frame" and accumulator
@@ -341,30 +223,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
         lds_f2 *slot = (lds_f2 *)(slots + wv * 2048);
         if (live) {
             // ---- merge (the inverse of the split), scaled by c = overlap-add normalisation / N, and conjugated for the inverse transform
-            const double hc = 0.5 * A.c;
-            double zmr[4], zmi[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double s2r = xkr[q] + xmr[q], s2i = xki[q] - xmi[q];     // X[k] + conj X[N - k] = 2 E
-                const double d2r = xkr[q] - xmr[q], d2i = xki[q] + xmi[q];     // X[k] - conj X[N - k] = 2 W^k O
-                const double vr = __builtin_fma(d2r, ws[q].x, d2i * ws[q].y), vi = __builtin_fma(d2i, ws[q].x, -(d2r * ws[q].y));   // conj(W^k) (.)
-                z.re[q] = hc * (s2r - vi); z.im[q] = -hc * (s2i + vr);         // conj Z'[k],      Z'[k]     = E + i O
-                zmr[q] = hc * (s2r + vi); zmi[q] = hc * (s2i - vr);            // conj Z'[N - k],  Z'[N - k] = conj(E - i O)
-            }
-            if (lane0) {
-                z.re[0] = hc * (xkr[0] + xmr[0]); z.im[0] = -hc * (xkr[0] - xmr[0]);   // conj Z'[0] = (X0 + XN)/2 - i (X0 - XN)/2
-                zmr[0] = A.c * Pr[0]; zmi[0] = A.c * Pi[0];                    // conj Z'[N/2] = conj conj X[N/2] = X[N/2]
-            }
-            wave_sync();
-#pragma unroll
-            for (int q = 0; q < 4; q++) xb[q * 64 + lane] = d2{zmr[q], zmi[q]};
-            wave_sync();
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const d2 v = xb[(3 - u) * 64 + pl]; z.re[4 + u] = v.x; z.im[4 + u] = v.y; }
-            if (lane0) {
-                z.re[4] = zmr[0]; z.im[4] = zmi[0]; z.re[5] = zmr[3]; z.im[5] = zmi[3];
-                z.re[6] = zmr[2]; z.im[6] = zmi[2]; z.re[7] = zmr[1]; z.im[7] = zmi[1];
-            }
+            rfft_merge_conj(z, xb, lane, (const d2 *)ws, X, A.c);
             fft512(z, xb, L);                                                  // y = FFT(conj Z'): x'[2n] = Re y, x'[2n + 1] = -Im y (1/N is in c)
             wave_sync();
 #pragma unroll

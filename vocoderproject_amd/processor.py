@@ -220,7 +220,8 @@ class BatchVocoderProcessor:
         self._chk(self.L.vp_set_time_parallel(self.h, int(bool(on))))
 
     def set_yin_mode(self, mode):
-        """"direct" (default, reference summation order) or "fft" (VP_YIN_FFT accelerator)."""
+        """"direct" (default: the reference's sums), "xcorr" (certified cross-correlation form, fused multiply-adds) or "fft" (the same
+        certified form with its cross-correlations by FFT where the build carries it); all three give the same output bits."""
         self._chk(self.L.vp_set_yin_mode(self.h, {"direct": 0, "fft": 1, "xcorr": 2, "xcorr_force_fallback": 3}[mode] if isinstance(mode, str) else int(mode)))
 
     def get_yin_mode(self):
