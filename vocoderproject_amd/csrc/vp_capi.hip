@@ -169,13 +169,16 @@ static PitchPlan pitch_plan(const vp_handle *h, bool fast, int nBlocks)
     return fast ? VP_PLAN(vp_k_pitch_fast, lds) : VP_PLAN(vp_k_pitch, lds);
 }
 // The certified cross-correlation YIN of the full-register common-case builds (vp_k_pitch_c, vp_k_pitch_fast_c, vp_k_pitch_fast_multi_c)
-// evaluates its cross-correlations by FFT (vp_pitch.inc xcorr_fft_wave; they carry no other form): one wavefront per forward transform,
-// two per 512-sample segment of the frame.  0: the launch does not use it.
+// evaluates its cross-correlations by FFT (vp_pitch.inc xcorr_fft_wave; they carry no other form): one wavefront and one exchange
+// buffer per forward transform, two per 512-sample segment of the frame.  0: the launch does not use it.
 static int pitch_xfft_waves(const vp_handle *h, bool fast, int nBlocks)
 {
     if (!pitch_common(h) || pitch_lite(h, fast) || (nBlocks > 1 && !fast)) return 0;
-    return 2 * (h->g.F >> 9);
+    int fw = 2 * (h->g.F >> 9);
+    if (const char *e = getenv("VP_XFFT_WAVES")) { const int v = atoi(e); if (v == fw / 2) fw = v; }     // diagnostic: one SEGMENT per wavefront (measured 2 % slower)
+    return fw;
 }
+static size_t pitch_xfft_lds(const vp_handle *h) { return vp_pitch_fft_lds_bytes(2 * (h->g.F >> 9)); }                  // (a buffer per TRANSFORM)
 #undef VP_PLAN
 
 extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
@@ -906,7 +909,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                     PitchPlan plan = pitch_plan(h, true, 1);
                     if (const int fw = f->cp.yinCert ? pitch_xfft_waves(h, true, 1) : 0) {
                         const size_t off = (plan.lds + 15) / 16 * 16;
-                        f->cp.fftOff = (int)off; f->cp.fftWaves = fw; plan.lds = off + vp_pitch_fft_lds_bytes(fw);
+                        f->cp.fftOff = (int)off; f->cp.fftWaves = fw; plan.lds = off + pitch_xfft_lds(h);
                     }
                     f->cp.ldsBytes = (int)plan.lds;
                     hipLaunchKernelGGL(plan.fn, dim3(f->n), dim3(512), plan.lds, h->auxStream, f->g, f->cp, f->dp, f->in, f->out);
@@ -987,7 +990,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 // one workgroup per CU anyway (S <= 256 or a frame beyond half a CU's LDS): the block's accumulator slice rides in LDS
                 // the block's accumulator slice in LDS when it fits beside the FFT cross-correlation's minimum (tables + one buffer)
                 const int fw = cp.yinCert ? pitch_xfft_waves(h, cp.iirFast != 0, nBlocks) : 0;
-                const size_t fftMin = fw ? vp_pitch_fft_lds_bytes(fw) + 16 : 0;
+                const size_t fftMin = fw ? pitch_xfft_lds(h) + 16 : 0;
                 if (nBlocks == 1 && !pitch_lite(h, cp.iirFast != 0) && plan.lds + vp_pitch_acc_lds_bytes(g) + 16 + fftMin <= h->ldsMax) {
                     cp.ldsAcc = 1;
                     plan.lds = ((plan.lds + 15) / 16) * 16 + vp_pitch_acc_lds_bytes(g);
@@ -995,7 +998,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 // certified YIN of the full-register common-case builds: tables and exchange buffers behind everything else
                 if (fw) {
                     const size_t off = (plan.lds + 15) / 16 * 16;
-                    cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + vp_pitch_fft_lds_bytes(fw);
+                    cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + pitch_xfft_lds(h);
                 }
                 cp.ldsBytes = (int)plan.lds;
                 hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
@@ -1214,7 +1217,7 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
         PitchPlan plan = pitch_plan(h, true, nb);
         if (const int fw = cp.yinCert ? pitch_xfft_waves(h, true, nb) : 0) {
             const size_t off = (plan.lds + 15) / 16 * 16;
-            cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + vp_pitch_fft_lds_bytes(fw);
+            cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + pitch_xfft_lds(h);
         }
         cp.ldsBytes = (int)plan.lds;
         ProfScope ps(h, st, 2);
