@@ -269,13 +269,13 @@ int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
 /* Diagnostic build only: ticks each of the first n streams' workgroups spent inside the pitch kernel (which stream paces a launch). */
 int vp_debug_read_stream_ticks(vp_handle *h, unsigned long long *out, int n, int reset);
 
-/* Standalone STFT round trip: sqrt-Hann window, batched FFT, [spectral stage], inverse FFT, overlap-add (frame_len a
- * power of two <= 4096, hop dividing it, at least two frames over every sample).  NO reference counterpart (the reference
- * contains no FFT): these are the STFT-shaped kernels BASELINE.json's north_star lists, reported on
- * their own by bench.py and checked against numpy.fft / a build-authored NumPy restatement (tests/stft_reference.py: parity
- * unpinned by nature).  1024-point frames run the fused kernel (csrc/vp_stft.hip: one frame per wavefront, the transform's
- * butterflies in registers, overlap-add in LDS, every input sample read from HBM once and every output sample written once);
- * other frame lengths a generic radix-2 pair of kernels.
+/* Standalone STFT round trip: sqrt-Hann window, batched FFT, [spectral stage], inverse FFT, overlap-add, in ONE fused kernel
+ * (csrc/vp_stft.hip: one frame per wavefront, the transform's butterflies in registers, overlap-add in LDS, every input sample
+ * read from HBM once and every output sample written once).  frame_len must be 1024 (eight complex points per lane of a
+ * wavefront; VP_ERR_GEOMETRY otherwise), hop a divisor of it with 2 <= frame_len / hop <= 16.  NO reference counterpart (the
+ * reference contains no FFT): these are the STFT-shaped kernels BASELINE.json's north_star lists, reported
+ * on their own by bench.py and checked against numpy.fft / a build-authored NumPy restatement (tests/stft_reference.py: parity
+ * unpinned by nature).
  * d_in/d_out: device float32 [n_streams][n_samples]; d_mag (optional): [n_streams][frames][frame_len/2+1]. */
 typedef struct vp_stft vp_stft;
 int vp_stft_create(int device, int n_streams, int n_samples, int frame_len, int hop, vp_stft **out);
@@ -285,10 +285,10 @@ int vp_stft_roundtrip(vp_stft *p, const float *d_in, float *d_out, float *d_mag,
 /* The north_star's "per-bin phase unwrap/accumulate" stage between the two transforms: the classic phase-vocoder pitch shift by
  * `semitones` in [-12, 12] (per frame and bin: magnitude and phase; phase advance against the previous frame minus the bin's
  * nominal advance, wrapped to (-pi, pi] -> true frequency; bins move to floor(k ratio + 0.5), magnitudes that land together
- * add; the synthesis phase accumulates the scaled advance).  Each call starts from a zero phase state.  Fused kernel only
- * (VP_ERR_GEOMETRY otherwise).  No reference counterpart; checked against tests/stft_reference.py. */
+ * add; the synthesis phase accumulates the scaled advance).  Each call starts from a zero phase state.  No reference counterpart;
+ * checked against tests/stft_reference.py. */
 int vp_stft_pitch_shift(vp_stft *p, const float *d_in, float *d_out, double semitones, void *hip_stream);
-int vp_stft_is_fused(const vp_stft *p);                      /* 1: vp_stft_roundtrip runs the fused kernel */
+int vp_stft_is_fused(const vp_stft *p);                      /* 1 (every handle runs the fused kernel; kept for older callers) */
 /* Diagnostic: cut every stream into this many runs of frames (one workgroup each) instead of choosing from the batch size
  * (0 = automatic).  The output does not depend on it (tests). */
 int vp_stft_set_runs(vp_stft *p, int runs_per_stream);

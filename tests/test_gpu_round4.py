@@ -297,14 +297,12 @@ def test_fused_stft_round_trip_against_numpy(hop, T):
         np.testing.assert_array_equal(y2, y, err_msg=f"runs={runs}")
 
 
-def test_generic_stft_kernels_still_serve_other_frame_lengths():
-    import stft_reference as R
-    for F, hop in ((512, 128), (2048, 512)):
-        x = _streams(3, F * 10)[:, 0].copy()
-        y, mag, st = _stft_run(x, F, hop, mag=True)
-        assert not st.fused
-        ref = np.stack([R.stft_roundtrip(x[s], F, hop) for s in range(3)])
-        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6)
+def test_stft_rejects_frame_lengths_the_fused_kernel_is_not_built_for():
+    from vocoderproject_amd import StftRoundTrip, VpError
+    for F, hop in ((512, 128), (2048, 512), (1024, 1024), (1024, 48)):
+        with pytest.raises(VpError) as e:
+            StftRoundTrip(2, 8192, F, hop)
+        assert e.value.code == -4                                    # VP_ERR_GEOMETRY
 
 
 @pytest.mark.parametrize("semitones", [3.0, -5.0, 12.0, -12.0, 0.0])

@@ -1540,50 +1540,34 @@ extern "C" int vp_set_yin_mode(vp_handle *h, int mode)
 }
 extern "C" int vp_get_yin_mode(const vp_handle *h) { return h ? h->yinMode : VP_ERR_INVALID_ARG; }
 
-// ---- standalone STFT round trip (no reference counterpart) ----------------------------------------------------------------------
-// 1024-point frames: the fused kernel of vp_stft.hip (one frame per wavefront, register FFT, overlap-add in LDS, optional phase-vocoder
-// stage); other power-of-two frame lengths: the generic pair vp_k_stft_frames / vp_k_stft_ola (radix-2 in LDS, frames through HBM).
+// ---- standalone STFT round trip (no reference counterpart): the fused kernel of vp_stft.hip -------------------------------------
+// (one frame per wavefront, register FFT, overlap-add in LDS, optional phase-vocoder stage; 1024-point frames)
 struct vp_stft {
-    int device, logF, F, hop, S, T, nFrames;
-    double *win = nullptr, *twRe = nullptr, *twIm = nullptr;
-    float *frames = nullptr;
+    int device, F, hop, S, T, nFrames;
+    double *win = nullptr, *tw1 = nullptr, *tw2 = nullptr, *tws = nullptr;
     float scale;
-    // fused kernel
-    bool fused = false;
-    double *tw1 = nullptr, *tw2 = nullptr, *tws = nullptr;
     int runsPerStream = 0;            // 0: chosen from the batch so that the grid fills the chip; > 0: vp_stft_set_runs (tests)
 };
 
 static void stft_free(vp_stft *p)
 {
-    (void)hipFree(p->win); (void)hipFree(p->twRe); (void)hipFree(p->twIm); (void)hipFree(p->frames);
-    (void)hipFree(p->tw1); (void)hipFree(p->tw2); (void)hipFree(p->tws);
+    (void)hipFree(p->win); (void)hipFree(p->tw1); (void)hipFree(p->tw2); (void)hipFree(p->tws);
 }
 
 extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int frame_len, int hop, vp_stft **out)
 {
     if (!out || n_streams <= 0 || frame_len < 8 || hop <= 0 || n_samples < frame_len) return VP_ERR_INVALID_ARG;
-    int lg = 0;
-    while ((1 << lg) < frame_len) lg++;
-    // (hop == frame_len: the sqrt-Hann windows do not overlap and w[0]^2 = 0 cannot be normalised; at least two frames must cover every sample)
-    if ((1 << lg) != frame_len || lg > 12 || frame_len % hop || frame_len / hop < 2) return VP_ERR_GEOMETRY;
+    // (hop == frame_len: the sqrt-Hann windows do not overlap and w[0]^2 = 0 cannot be normalised; at least two frames must cover every
+    // sample.  Frame lengths other than 1024 -- eight complex points per lane of one wavefront -- are not built.)
+    if (!vp_stft_supported(frame_len, hop)) return VP_ERR_GEOMETRY;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return VP_ERR_NO_DEVICE;
-    const bool fused = vp_stft_supported(frame_len, hop) != 0;
-    if (!fused) {   // 4096-point frames need 96 KB of dynamic LDS: above the default ceiling of the function
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, (const void *)vp_k_stft_frames) != hipSuccess ||
-            hipFuncSetAttribute((const void *)vp_k_stft_frames, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(160 * 1024 - fa.sharedSizeBytes)) != hipSuccess)
-            return VP_ERR_HIP;
-    }
     vp_stft *p = new vp_stft();
-    p->device = device; p->logF = lg; p->F = frame_len; p->hop = hop; p->S = n_streams; p->T = n_samples;
+    p->device = device; p->F = frame_len; p->hop = hop; p->S = n_streams; p->T = n_samples;
     p->nFrames = (n_samples - frame_len) / hop + 1;
-    p->fused = fused;
     const double PI = 3.141592653589793238;
-    std::vector<double> w(frame_len), tr(frame_len / 2), ti(frame_len / 2);
+    std::vector<double> w(frame_len);
     double sumsq = 0;                                             // sum over one hop grid of w^2 (constant for periodic Hann)
     for (int i = 0; i < frame_len; i++) w[i] = std::sqrt(0.5 - 0.5 * std::cos(2.0 * PI * i / frame_len));
     for (int i = 0; i < frame_len; i += hop) sumsq += w[i] * w[i];
@@ -1591,31 +1575,20 @@ extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int fram
     auto up = [](double **d, const std::vector<double> &v) {
         return hipMalloc(d, v.size() * 8) == hipSuccess && hipMemcpy(*d, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
     };
-    bool ok = up(&p->win, w);
-    if (fused) {
-        // per-lane twiddles of the wavefront transform (vp_stft.hip fft512) and of the real-input split, host libm
-        std::vector<double> t1(64 * 8 * 2), t2(64 * 8 * 2), ts(64 * 4 * 2);
-        for (int lane = 0; lane < 64; lane++) {
-            for (int r = 0; r < 8; r++) {
-                const double a1 = -2.0 * PI * (double)(r * (lane >> 3)) / 64.0, a2 = -2.0 * PI * (double)(r * lane) / 512.0;
-                t1[(lane * 8 + r) * 2] = std::cos(a1); t1[(lane * 8 + r) * 2 + 1] = std::sin(a1);
-                t2[(lane * 8 + r) * 2] = std::cos(a2); t2[(lane * 8 + r) * 2 + 1] = std::sin(a2);
-            }
-            for (int q = 0; q < 4; q++) {
-                const double a = -2.0 * PI * (double)(64 * q + lane) / 1024.0;
-                ts[(lane * 4 + q) * 2] = std::cos(a); ts[(lane * 4 + q) * 2 + 1] = std::sin(a);
-            }
+    // per-lane twiddles of the wavefront transform (vp_fft.inc fft512) and of the real-input split, host libm
+    std::vector<double> t1(64 * 8 * 2), t2(64 * 8 * 2), ts(64 * 4 * 2);
+    for (int lane = 0; lane < 64; lane++) {
+        for (int r = 0; r < 8; r++) {
+            const double a1 = -2.0 * PI * (double)(r * (lane >> 3)) / 64.0, a2 = -2.0 * PI * (double)(r * lane) / 512.0;
+            t1[(lane * 8 + r) * 2] = std::cos(a1); t1[(lane * 8 + r) * 2 + 1] = std::sin(a1);
+            t2[(lane * 8 + r) * 2] = std::cos(a2); t2[(lane * 8 + r) * 2 + 1] = std::sin(a2);
         }
-        ok = ok && up(&p->tw1, t1) && up(&p->tw2, t2) && up(&p->tws, ts);
-    } else {
-        for (int j = 0; j < frame_len / 2; j++) {
-            double a = -2.0 * PI * j / frame_len;
-            tr[j] = std::cos(a); ti[j] = std::sin(a);
+        for (int q = 0; q < 4; q++) {
+            const double a = -2.0 * PI * (double)(64 * q + lane) / 1024.0;
+            ts[(lane * 4 + q) * 2] = std::cos(a); ts[(lane * 4 + q) * 2 + 1] = std::sin(a);
         }
-        ok = ok && up(&p->twRe, tr) && up(&p->twIm, ti) &&
-             hipMalloc(&p->frames, (size_t)n_streams * p->nFrames * frame_len * sizeof(float)) == hipSuccess;
     }
-    if (!ok) { stft_free(p); delete p; return VP_ERR_OOM; }
+    if (!(up(&p->win, w) && up(&p->tw1, t1) && up(&p->tw2, t2) && up(&p->tws, ts))) { stft_free(p); delete p; return VP_ERR_OOM; }
     *out = p;
     return VP_OK;
 }
@@ -1631,7 +1604,7 @@ extern "C" int vp_stft_destroy(vp_stft *p)
 }
 
 extern "C" int vp_stft_num_frames(const vp_stft *p) { return p ? p->nFrames : VP_ERR_INVALID_ARG; }
-extern "C" int vp_stft_is_fused(const vp_stft *p) { return p ? (p->fused ? 1 : 0) : VP_ERR_INVALID_ARG; }
+extern "C" int vp_stft_is_fused(const vp_stft *p) { return p ? 1 : VP_ERR_INVALID_ARG; }
 extern "C" int vp_stft_set_runs(vp_stft *p, int runs_per_stream)
 {
     if (!p || runs_per_stream < 0) return VP_ERR_INVALID_ARG;
@@ -1668,21 +1641,13 @@ extern "C" int vp_stft_roundtrip(vp_stft *p, const float *d_in, float *d_out, fl
 {
     if (!p || !d_in || !d_out) return VP_ERR_INVALID_ARG;
     if (hipSetDevice(p->device) != hipSuccess) return VP_ERR_NO_DEVICE;
-    hipStream_t st = (hipStream_t)hip_stream;
-    if (p->fused) return stft_fused(p, d_in, d_out, d_mag, st, false, 1.0);
-    const size_t lds = (size_t)3 * p->F * sizeof(double);
-    hipLaunchKernelGGL(vp_k_stft_frames, dim3(p->nFrames, p->S), dim3(256), lds, st, d_in, p->frames, d_mag, p->win, p->twRe, p->twIm,
-                       p->T, p->nFrames, p->logF, p->hop);
-    hipLaunchKernelGGL(vp_k_stft_ola, dim3(std::min(64, (p->T + 255) / 256), p->S), dim3(256), 0, st, p->frames, d_out, p->T, p->nFrames,
-                       p->F, p->hop, p->scale);
-    return hipGetLastError() == hipSuccess ? VP_OK : VP_ERR_HIP;
+    return stft_fused(p, d_in, d_out, d_mag, (hipStream_t)hip_stream, false, 1.0);
 }
 
 // the same round trip with the phase-vocoder pitch shift between the transforms (fused kernel only)
 extern "C" int vp_stft_pitch_shift(vp_stft *p, const float *d_in, float *d_out, double semitones, void *hip_stream)
 {
     if (!p || !d_in || !d_out || !(semitones >= -12.0 && semitones <= 12.0)) return VP_ERR_INVALID_ARG;
-    if (!p->fused) return VP_ERR_GEOMETRY;
     if (hipSetDevice(p->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     return stft_fused(p, d_in, d_out, nullptr, (hipStream_t)hip_stream, true, std::pow(2.0, semitones / 12.0));
 }

@@ -32,9 +32,3 @@ static inline size_t vp_voc_lds_bytes(int W, int nWaves)
 {
     return (VP_VOC_SHARED_DOUBLES(W) + (size_t)nWaves * voc_wave_doubles(W)) * sizeof(double);
 }
-
-__global__ void vp_k_stft_frames(const float *__restrict__ in, float *__restrict__ frames, float *__restrict__ mag,
-                                 const double *__restrict__ win, const double *__restrict__ twRe, const double *__restrict__ twIm,
-                                 int nSamples, int nFrames, int logF, int hop);
-__global__ void vp_k_stft_ola(const float *__restrict__ frames, float *__restrict__ out, int nSamples, int nFrames, int F, int hop,
-                              float scale);

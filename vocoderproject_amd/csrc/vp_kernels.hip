@@ -18,7 +18,7 @@
 
 // The kernels are template instantiations of two large bodies; the build compiles this file several times side by side,
 // each translation unit keeping one group of them (-DVP_TU=k; 0 or undefined: all of them, e.g. for -S listings).
-//   1: ingest/gate, vocoder, emit, STFT   2: vp_k_pitch   3: vp_k_pitch_fast   4: vp_k_pitch_multi, vp_k_pitch_fast_multi
+//   1: ingest/gate, vocoder, emit   2: vp_k_pitch   3: vp_k_pitch_fast   4: vp_k_pitch_multi, vp_k_pitch_fast_multi
 //   5: vp_k_pitch_lite, vp_k_pitch_lite_fast
 #ifndef VP_TU
 #define VP_TU 0
@@ -28,8 +28,9 @@
 
 #define WAVE 64
 
-// Orders from VP_LEV_SCALAR_MIN to 48 take the register-resident Levinson-Durbin (levinson_scalar).  Measured on one box
-// (tools/abn.sh): order 48 (configs[4]) pitch kernel +5 %, vocoder +8 %; at order 40 the wave-distributed form is 7 % faster.
+// The workgroup vocoder's orders from VP_LEV_SCALAR_MIN to 48 take the register-resident Levinson-Durbin (levinson_scalar).  Measured
+// on one box (tools/abn.sh): order 48 (configs[4]) +8 %; at order 40 the wave-distributed form is 7 % faster.  (The pitch kernel's
+// orders 16..48 take the three-register row forms levinson_row48 / levinson_fast64.)
 #ifndef VP_LEV_SCALAR_MIN
 #define VP_LEV_SCALAR_MIN 41
 #endif
@@ -74,9 +75,6 @@ __device__ unsigned long long vp_last_w[16];
 #define STAMP0(D) do { } while (0)
 #endif
 
-#ifndef VP_LEV_ROW48
-#define VP_LEV_ROW48 1          /* orders 16..48 of the pitch LPC: the three-register row form (levinson_row48); 0 = the forms it replaced */
-#endif
 #ifndef VP_LPC_FAST
 #define VP_LPC_FAST 1           /* VP_IIR_FAST: LPC autocorrelation with the sum over n split across the lanes (autocorr_rows_fast); 0 = the ordered sums */
 #endif
@@ -100,9 +98,6 @@ __device__ unsigned long long vp_last_w[16];
 #endif
 #ifndef VP_FIR4_SELECT
 #define VP_FIR4_SELECT 1        /* fir4: the filter's first outputs as the four-chain select form (0 = the scalar loop) */
-#endif
-#ifndef VP_LPC_HAND15
-#define VP_LPC_HAND15 0         /* FAST, orders below 16: 1 = LPC autocorrelation on wave 6, Levinson-Durbin on wave 7 (measured neutral: 16.2 M either way) */
 #endif
 #ifndef VP_HC_WAVE
 #define VP_HC_WAVE 5
@@ -318,54 +313,5 @@ __device__ __forceinline__ void emit_block(const VpGeom &g, const VpCall &c, con
 __global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out)
 {
     emit_block(g, c, d, out);
-}
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// Standalone STFT round trip (NO reference counterpart -- the reference has no FFT, SURVEY.md section 0;
-// this is the "Hann windowing, batched radix-2 FFT/iFFT, overlap-add" kernel BASELINE.json's
-// north_star names, reported separately).  One workgroup per (stream, frame): sqrt-Hann analysis
-// window, forward FFT, [identity spectral stage, optional magnitude dump], inverse FFT, sqrt-Hann
-// synthesis window -> frame scratch; a second kernel overlap-adds in gather form (deterministic).
-#if VP_TU_HAS(1)
-__global__ __launch_bounds__(256) void vp_k_stft_frames(const float *__restrict__ in, float *__restrict__ frames,
-                                                        float *__restrict__ mag, const double *__restrict__ win,
-                                                        const double *__restrict__ twRe, const double *__restrict__ twIm,
-                                                        int nSamples, int nFrames, int logF, int hop)
-{
-    extern __shared__ double smem[];
-    const int F = 1 << logF, tid = threadIdx.x, nt = blockDim.x;
-    const int s = blockIdx.y, f = blockIdx.x;
-    lds_f64 *zr = (lds_f64 *)smem, *zi = zr + F, *twr = zi + F, *twi = twr + (F >> 1);
-    const float *x = in + (size_t)s * nSamples + (size_t)f * hop;
-    for (int j = tid; j < (F >> 1); j += nt) { twr[j] = twRe[j]; twi[j] = twIm[j]; }
-    for (int j = tid; j < F; j += nt) { zr[j] = (double)x[j] * win[j]; zi[j] = 0.0; }
-    __syncthreads();
-    fft_forward_dif(zr, zi, logF, (const lds_f64 *)twr, (const lds_f64 *)twi);
-    if (mag) {                                                       // |X[k]|, k <= F/2 (natural order)
-        float *m = mag + ((size_t)s * nFrames + f) * ((F >> 1) + 1);
-        for (int k = tid; k <= (F >> 1); k += nt) { const int p = bitrev(k, logF); m[k] = (float)sqrt(zr[p] * zr[p] + zi[p] * zi[p]); }
-    }
-    fft_inverse_dit(zr, zi, logF, (const lds_f64 *)twr, (const lds_f64 *)twi);
-    float *o = frames + ((size_t)s * nFrames + f) * F;
-    const double invF = 1.0 / (double)F;
-    for (int j = tid; j < F; j += nt) o[j] = (float)(zr[j] * invF * win[j]);
-}
-#endif
-
-#if VP_TU_HAS(1)
-__global__ __launch_bounds__(256) void vp_k_stft_ola(const float *__restrict__ frames, float *__restrict__ out, int nSamples,
-                                                     int nFrames, int F, int hop, float scale)
-{
-    const int s = blockIdx.y;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nSamples; t += gridDim.x * blockDim.x) {
-        const int fhi = min(nFrames - 1, t / hop), flo = max(0, (t - F + hop) / hop);
-        float acc = 0.f;
-        for (int f = flo; f <= fhi; f++) {
-            const int j = t - f * hop;
-            if (j >= 0 && j < F) acc += frames[((size_t)s * nFrames + f) * F + j];
-        }
-        out[(size_t)s * nSamples + t] = acc * scale;
-    }
 }
 #endif

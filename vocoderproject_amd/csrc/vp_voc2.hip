@@ -21,9 +21,6 @@
 // Every kernel is bit-identical to vp_k_vocoder in VP_IIR_EXACT mode (tests/test_gpu_round2.py); in VP_IIR_FAST mode the
 // recursion is the block form the pitch kernel uses (tolerance-tested).  Citations: file:line under /root/reference/Source/.
 #define VP_TU 99                 // vp_kernels.hip's device helpers without any of its kernels
-#ifndef VP_V2_AC_WIN_LDS
-#define VP_V2_AC_WIN_LDS 0
-#endif
 #include "vp_kernels.hip"
 
 #include <algorithm>
@@ -159,13 +156,9 @@ __global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev
         // reads a few samples past the window: inside the tile's padding, never used).
         // (round 3) the window function of the main loop through SCALAR loads: every index is wave-uniform and inside [0, W), so the
         // values arrive in SGPRs and feed the multiplies as their one scalar operand -- the loop then holds no LDS instruction at
-        // all (19 broadcast reads per 8-element trip at ~8 ns of issue each were 40 % of the trip).  VP_V2_AC_WIN_LDS=1: the LDS copy.
-#if VP_V2_AC_WIN_LDS
-#define V2_AC_WIN(I) wl[I]
-#else
+        // all (19 broadcast reads per 8-element trip at ~8 ns of issue each were 40 % of the trip; the LDS copy below serves the tail).
         const double *__restrict__ wg = d.vocWin;
 #define V2_AC_WIN(I) wg[I]
-#endif
         double R[16];
 #pragma unroll
         for (int t = 0; t < L; t++) R[t] = FS ? (double)x[m0 + t] * V2_AC_WIN(m0 + t) : (double)x[m0 + t];
