@@ -62,7 +62,7 @@ PROFILE_EVERY = 8       # kernel durations are sampled live inside the timed reg
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9
 HBM_PEAK_GBS = 8000.0                                                  # MI355X_MICROARCH.md
 UNIQUE_BLOCKS = 16                                                      # synthetic input ring, cycled
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r03_counters.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r04_counters.json")
 
 
 def usable_cores():
@@ -91,7 +91,7 @@ def kernel_source_hash():
 
 
 def committed_counters(kernel, workload_key):
-    """Per-launch PMC figures of `kernel` at `workload_key` from profiles/r03_counters.json (tools/collect_counters.sh:
+    """Per-launch PMC figures of `kernel` at `workload_key` from profiles/r04_counters.json (tools/collect_counters.sh:
     separate rocprofv3 --pmc passes of this very command); None unless kernel build name AND source hash match."""
     try:
         with open(COUNTERS_JSON) as f:
@@ -218,7 +218,7 @@ STFT_FP64_OPS_PER_FRAME = {"v_add_f64": 378, "v_mul_f64": 163, "v_fmac_f64": 72}
 FP64_VECTOR_PEAK_TFLOPS = 78.6                                          # MI355X: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 
 
-def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30):
+def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True):
     """Standalone fused STFT->iSTFT kernel (Hann, FFT, iFFT, OLA in one launch; csrc/vp_stft.hip): NO reference counterpart, reported
     apart from the metric, with its own roofline: HBM on the algorithmic 2048 B per frame (every input
     sample in once, every output sample out once) and the fp64 vector share."""
@@ -246,12 +246,18 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30):
            "us_per_call": dt * 1e6,
            "note": "standalone fused STFT round trip (sqrt-Hann, 512-pt complex register FFT per wavefront, iFFT, overlap-add in LDS); fp64; no reference counterpart",
            "roofline": {"bound": "hbm", "achieved": fps * alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps * alg / 1e9 / HBM_PEAK_GBS,
-                        "alg_bytes_per_frame": alg, "traffic": None},
+                        "alg_bytes_per_frame": alg, "alg_bytes_per_launch": alg * frames, "traffic": None},
            "fp64_valu": {"insts_per_frame_per_lane": insts, "flop_per_frame": flops, "tflops": fps * flops / 1e12,
                          "frac_of_peak_flops": fps * flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                          "frac_of_issue_slots": fps * insts * 64 / VALU_LANE_OPS_PEAK,
                          "what": "fp64 vector instructions per frame counted in the kernel's ISA (straight-line loop body) x frames/s, against "
                                  "78.6 TFLOP/s (FMA = 2) and against the fp64 issue slots (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz)"}}
+    ctr = committed_counters("vp_k_stft_fused<false, false>", f"stft/S{S}/T{T}/F{F}/hop{hop}")
+    if ctr:                                                     # HBM bytes per launch from the committed PMC passes of this build (FETCH x 2 + WRITE)
+        out["roofline"]["traffic"] = ctr.get("hbm_bytes_per_launch")
+        out["roofline"]["rocprof_avg_us"] = ctr.get("rocprof_avg_us")
+    if not pv:
+        return out
     # the phase-vocoder stage between the transforms (vp_stft_pitch_shift, +7 semitones): one workgroup per stream
     if st.fused:
         for _ in range(2):
@@ -357,6 +363,8 @@ def main():
     ap.add_argument("--voc-window", default=None, choices=["512/128", "1024/256"],
                     help="vocoder window/hop: the reference's own 512/128 (default) or the metric's 1024/256 (SURVEY section 8, cfg 3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--stft-only", action="store_true",
+                    help="time the standalone fused STFT kernel alone and print its figure (one kernel population: for the rocprofv3 passes)")
     ap.add_argument("--no-parity", action="store_true", help="skip the per-leg comparison with the CPU oracle")
     ap.add_argument("--parity-streams", type=int, default=8, help="streams of each leg's batch that are run through the CPU oracle")
     ap.add_argument("--parity-blocks", type=int, default=12, help="blocks per stream of that comparison")
@@ -405,6 +413,13 @@ def main():
                 "rank_sum_expected": world * (world - 1) / 2.0}
     n_gpus = world
 
+    if args.stft_only:
+        fig = stft_figure(dev, args.streams, reps=max(args.steps, 10), pv=False)
+        T = 1024 * 64
+        line = {"stft_only": True, "value": fig["frames_per_s"], "unit": "frames/s", "kernel_us": {fig["kernel"]: fig["us_per_call"]},
+                "config": {"workload_key": f"stft/S{args.streams}/T{T}/F1024/hop256", "workload": fig["workload"]}, "stft_kernel": fig}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        return
     S, N, mode = args.streams, args.block, args.mode
     global FS, HOP
     if args.cfg5:

@@ -16,11 +16,11 @@ run() {
   name=$1; shift
   mkdir -p $out/$name
   echo "$@" > $out/$name/args.txt
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/kt -- python3 bench.py --steps 40 --warmup 4 --no-cpu --single-mode "$@" > $out/$name/bench_under_rocprof.json 2> $out/$name/kt.err
-  rocprofv3 --pmc $SQ --output-format csv -d $out/$name/sq -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/sq.err
-  rocprofv3 --pmc $SQ2 --output-format csv -d $out/$name/sq2 -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/sq2.err
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$name/fetch -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/fetch.err
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$name/write -- python3 bench.py --steps 24 --warmup 4 --no-cpu --single-mode "$@" > /dev/null 2> $out/$name/write.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/kt -- python3 bench.py --steps 40 --warmup 4 --no-cpu --no-parity --single-mode "$@" > $out/$name/bench_under_rocprof.json 2> $out/$name/kt.err
+  rocprofv3 --pmc $SQ --output-format csv -d $out/$name/sq -- python3 bench.py --steps 24 --warmup 4 --no-cpu --no-parity --single-mode "$@" > /dev/null 2> $out/$name/sq.err
+  rocprofv3 --pmc $SQ2 --output-format csv -d $out/$name/sq2 -- python3 bench.py --steps 24 --warmup 4 --no-cpu --no-parity --single-mode "$@" > /dev/null 2> $out/$name/sq2.err
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$name/fetch -- python3 bench.py --steps 24 --warmup 4 --no-cpu --no-parity --single-mode "$@" > /dev/null 2> $out/$name/fetch.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$name/write -- python3 bench.py --steps 24 --warmup 4 --no-cpu --no-parity --single-mode "$@" > /dev/null 2> $out/$name/write.err
 }
 sel=${2:-all}
 [ $sel = all -o $sel = cfg2 ] && run cfg2_pitch_s256
@@ -28,6 +28,7 @@ sel=${2:-all}
 [ $sel = all -o $sel = cfg4 ] && run cfg4_both_s1024 --mode both --streams 1024
 [ $sel = all -o $sel = cfg5 ] && run cfg5_both_s512 --cfg5 --mode both --streams 512
 [ $sel = all -o $sel = cfg2x ] && run cfg2_pitch_s256_exact --iir exact
+[ $sel = all -o $sel = stft ] && run stft_s256 --stft-only
 python3 tools/summarize_counters.py $out $tag
 # the summary as this box computed it travels back with gpurun_out/ (copy gpurun_out/ctr_<tag>/_profiles/* into profiles/)
 mkdir -p $out/_profiles

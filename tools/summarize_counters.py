@@ -61,8 +61,11 @@ def main():
         except (OSError, ValueError, IndexError):
             continue
         cfg = line["config"]
-        mono = cfg["input"].startswith("mono")
-        wkey = f"{'cfg5' if 'configs[4]' in cfg['workload'] else 'cfg'}/{cfg['mode']}{'-mono' if mono else ''}/S{cfg['streams_per_gpu']}/N{cfg['block']}/{cfg['iir_mode']}/{cfg['yin_mode']}"
+        if line.get("stft_only"):
+            wkey = cfg["workload_key"]
+        else:
+            mono = cfg["input"].startswith("mono")
+            wkey = f"{'cfg5' if 'configs[4]' in cfg['workload'] else 'cfg'}/{cfg['mode']}{'-mono' if mono else ''}/S{cfg['streams_per_gpu']}/N{cfg['block']}/{cfg['iir_mode']}/{cfg['yin_mode']}"
         ks, ksf = kernel_stats(os.path.join(cdir, "kt"))
         if ksf:
             shutil.copy(ksf, os.path.join(prof, f"{tag}_{name}_kernel_stats.csv"))
