@@ -258,6 +258,19 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True):
         out["roofline"]["rocprof_avg_us"] = ctr.get("rocprof_avg_us")
     if not pv:
         return out
+    # BASELINE configs[4]'s geometry for this kernel: 2048-point frames, hop 512 (sixteen complex points per lane: vp_k_stft_fused2k)
+    st2 = StftRoundTrip(S, T, 2048, 512, device=dev.index or 0)
+    for _ in range(2):
+        st2(x, y)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(max(4, reps // 3)):
+        st2(x, y)
+    torch.cuda.synchronize(dev)
+    dt2 = (time.perf_counter() - t0) / max(4, reps // 3)
+    out["frames_2048_hop_512"] = {"frames_per_s": S * st2.n_frames / dt2, "us_per_call": dt2 * 1e6, "kernel": "vp_k_stft_fused2k<false>",
+                                  "hbm_gbs_algorithmic": S * st2.n_frames * 2 * 512 * 4 / dt2 / 1e9}
+    st2.close()
     # the phase-vocoder stage between the transforms (vp_stft_pitch_shift, +7 semitones): one workgroup per stream
     if st.fused:
         for _ in range(2):

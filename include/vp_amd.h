@@ -271,8 +271,8 @@ int vp_debug_read_stream_ticks(vp_handle *h, unsigned long long *out, int n, int
 
 /* Standalone STFT round trip: sqrt-Hann window, batched FFT, [spectral stage], inverse FFT, overlap-add, in ONE fused kernel
  * (csrc/vp_stft.hip: one frame per wavefront, the transform's butterflies in registers, overlap-add in LDS, every input sample
- * read from HBM once and every output sample written once).  frame_len must be 1024 (eight complex points per lane of a
- * wavefront; VP_ERR_GEOMETRY otherwise), hop a divisor of it with 2 <= frame_len / hop <= 16.  NO reference counterpart (the
+ * read from HBM once and every output sample written once).  frame_len must be 1024 or 2048 (eight / sixteen complex points
+ * per lane of a wavefront; VP_ERR_GEOMETRY otherwise), hop a divisor of it with 2 <= frame_len / hop <= 16.  NO reference counterpart (the
  * reference contains no FFT): these are the STFT-shaped kernels BASELINE.json's north_star lists, reported
  * on their own by bench.py and checked against numpy.fft / a build-authored NumPy restatement (tests/stft_reference.py: parity
  * unpinned by nature).
@@ -285,8 +285,8 @@ int vp_stft_roundtrip(vp_stft *p, const float *d_in, float *d_out, float *d_mag,
 /* The north_star's "per-bin phase unwrap/accumulate" stage between the two transforms: the classic phase-vocoder pitch shift by
  * `semitones` in [-12, 12] (per frame and bin: magnitude and phase; phase advance against the previous frame minus the bin's
  * nominal advance, wrapped to (-pi, pi] -> true frequency; bins move to floor(k ratio + 0.5), magnitudes that land together
- * add; the synthesis phase accumulates the scaled advance).  Each call starts from a zero phase state.  No reference counterpart;
- * checked against tests/stft_reference.py. */
+ * add; the synthesis phase accumulates the scaled advance).  Each call starts from a zero phase state.  1024-point frames only
+ * (VP_ERR_GEOMETRY otherwise).  No reference counterpart; checked against tests/stft_reference.py. */
 int vp_stft_pitch_shift(vp_stft *p, const float *d_in, float *d_out, double semitones, void *hip_stream);
 int vp_stft_is_fused(const vp_stft *p);                      /* 1 (every handle runs the fused kernel; kept for older callers) */
 /* Diagnostic: cut every stream into this many runs of frames (one workgroup each) instead of choosing from the batch size

@@ -270,13 +270,14 @@ def _stft_run(x, F, hop, runs=0, mag=False, semitones=None):
     return yd.cpu().numpy(), (md.cpu().numpy() if mag else None), st
 
 
-@pytest.mark.parametrize("hop,T", [(256, 1024 * 24), (256, 1024 * 9 + 300), (512, 1024 * 12), (128, 1024 * 6 + 128), (256, 4097), (64, 5000)])
-def test_fused_stft_round_trip_against_numpy(hop, T):
+@pytest.mark.parametrize("F,hop,T", [(1024, 256, 1024 * 24), (1024, 256, 1024 * 9 + 300), (1024, 512, 1024 * 12), (1024, 128, 1024 * 6 + 128), (1024, 256, 4097),
+                                     (1024, 64, 5000), (2048, 512, 2048 * 12), (2048, 512, 2048 * 5 + 1234), (2048, 1024, 2048 * 6), (2048, 256, 9001)])
+def test_fused_stft_round_trip_against_numpy(F, hop, T):
     """Whole output (edges included) against tests/stft_reference.py, the magnitude spectrum against numpy.fft.rfft, every sample
     written exactly once (NaN prefill), odd lengths (the unaligned load path), overlap factors 2 / 4 / 8 / 16 -- and the partition of a
     stream into runs of frames must not change a single bit (a run recomputes the frames in front of it in the same order)."""
     import stft_reference as R
-    F, S = 1024, 5
+    S = 5
     x = _streams(S, T)[:, 0].copy()
     x[1] *= 3.0
     y, mag, st = _stft_run(x, F, hop, mag=True)
@@ -299,7 +300,7 @@ def test_fused_stft_round_trip_against_numpy(hop, T):
 
 def test_stft_rejects_frame_lengths_the_fused_kernel_is_not_built_for():
     from vocoderproject_amd import StftRoundTrip, VpError
-    for F, hop in ((512, 128), (2048, 512), (1024, 1024), (1024, 48)):
+    for F, hop in ((512, 128), (4096, 1024), (1024, 1024), (1024, 48), (2048, 96)):
         with pytest.raises(VpError) as e:
             StftRoundTrip(2, 8192, F, hop)
         assert e.value.code == -4                                    # VP_ERR_GEOMETRY

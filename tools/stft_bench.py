@@ -31,3 +31,5 @@ if __name__ == "__main__":
     run(1024, 65536, semitones=7.0)
     run(256, 65536, hop=512)
     run(256, 65536, hop=128)
+    run(256, 65536, F=2048, hop=512)          # BASELINE configs[4]'s "2048-pt FFT hop 512"
+    run(1024, 65536, F=2048, hop=512)

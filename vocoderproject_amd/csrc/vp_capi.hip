@@ -1541,24 +1541,24 @@ extern "C" int vp_set_yin_mode(vp_handle *h, int mode)
 extern "C" int vp_get_yin_mode(const vp_handle *h) { return h ? h->yinMode : VP_ERR_INVALID_ARG; }
 
 // ---- standalone STFT round trip (no reference counterpart): the fused kernel of vp_stft.hip -------------------------------------
-// (one frame per wavefront, register FFT, overlap-add in LDS, optional phase-vocoder stage; 1024-point frames)
+// (one frame per wavefront, register FFT, overlap-add in LDS; 1024-point frames, optionally with the phase-vocoder stage, and 2048-point frames)
 struct vp_stft {
     int device, F, hop, S, T, nFrames;
-    double *win = nullptr, *tw1 = nullptr, *tw2 = nullptr, *tws = nullptr;
+    double *win = nullptr, *tw1 = nullptr, *tw2 = nullptr, *tws = nullptr, *twTop = nullptr;
     float scale;
     int runsPerStream = 0;            // 0: chosen from the batch so that the grid fills the chip; > 0: vp_stft_set_runs (tests)
 };
 
 static void stft_free(vp_stft *p)
 {
-    (void)hipFree(p->win); (void)hipFree(p->tw1); (void)hipFree(p->tw2); (void)hipFree(p->tws);
+    (void)hipFree(p->win); (void)hipFree(p->tw1); (void)hipFree(p->tw2); (void)hipFree(p->tws); (void)hipFree(p->twTop);
 }
 
 extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int frame_len, int hop, vp_stft **out)
 {
     if (!out || n_streams <= 0 || frame_len < 8 || hop <= 0 || n_samples < frame_len) return VP_ERR_INVALID_ARG;
     // (hop == frame_len: the sqrt-Hann windows do not overlap and w[0]^2 = 0 cannot be normalised; at least two frames must cover every
-    // sample.  Frame lengths other than 1024 -- eight complex points per lane of one wavefront -- are not built.)
+    // sample.  Frame lengths other than 1024 and 2048 -- eight / sixteen complex points per lane of one wavefront -- are not built.)
     if (!vp_stft_supported(frame_len, hop)) return VP_ERR_GEOMETRY;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
@@ -1575,20 +1575,24 @@ extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int fram
     auto up = [](double **d, const std::vector<double> &v) {
         return hipMalloc(d, v.size() * 8) == hipSuccess && hipMemcpy(*d, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
     };
-    // per-lane twiddles of the wavefront transform (vp_fft.inc fft512) and of the real-input split, host libm
-    std::vector<double> t1(64 * 8 * 2), t2(64 * 8 * 2), ts(64 * 4 * 2);
+    // per-lane twiddles of the wavefront transform (vp_fft.inc fft512), of the real-input split (NP = F / 256 bin pairs per lane:
+    // W_F^(64 q + lane)) and, for 2048-point frames, of the radix-2 step on top of two 512-point transforms (W_1024^(64 q + lane)), host libm
+    const int NP = frame_len / 256;
+    std::vector<double> t1(64 * 8 * 2), t2(64 * 8 * 2), ts(64 * NP * 2), tt(64 * 8 * 2);
     for (int lane = 0; lane < 64; lane++) {
         for (int r = 0; r < 8; r++) {
             const double a1 = -2.0 * PI * (double)(r * (lane >> 3)) / 64.0, a2 = -2.0 * PI * (double)(r * lane) / 512.0;
+            const double a3 = -2.0 * PI * (double)(64 * r + lane) / 1024.0;
             t1[(lane * 8 + r) * 2] = std::cos(a1); t1[(lane * 8 + r) * 2 + 1] = std::sin(a1);
             t2[(lane * 8 + r) * 2] = std::cos(a2); t2[(lane * 8 + r) * 2 + 1] = std::sin(a2);
+            tt[(lane * 8 + r) * 2] = std::cos(a3); tt[(lane * 8 + r) * 2 + 1] = std::sin(a3);
         }
-        for (int q = 0; q < 4; q++) {
-            const double a = -2.0 * PI * (double)(64 * q + lane) / 1024.0;
-            ts[(lane * 4 + q) * 2] = std::cos(a); ts[(lane * 4 + q) * 2 + 1] = std::sin(a);
+        for (int q = 0; q < NP; q++) {
+            const double a = -2.0 * PI * (double)(64 * q + lane) / (double)frame_len;
+            ts[(lane * NP + q) * 2] = std::cos(a); ts[(lane * NP + q) * 2 + 1] = std::sin(a);
         }
     }
-    if (!(up(&p->win, w) && up(&p->tw1, t1) && up(&p->tw2, t2) && up(&p->tws, ts))) { stft_free(p); delete p; return VP_ERR_OOM; }
+    if (!(up(&p->win, w) && up(&p->tw1, t1) && up(&p->tw2, t2) && up(&p->tws, ts) && (frame_len != 2048 || up(&p->twTop, tt)))) { stft_free(p); delete p; return VP_ERR_OOM; }
     *out = p;
     return VP_OK;
 }
@@ -1616,14 +1620,16 @@ static int stft_fused(vp_stft *p, const float *d_in, float *d_out, float *d_mag,
 {
     VpStftArgs a;
     memset(&a, 0, sizeof a);
-    a.in = d_in; a.out = d_out; a.mag = d_mag; a.win = p->win; a.tw1 = p->tw1; a.tw2 = p->tw2; a.tws = p->tws;
+    a.in = d_in; a.out = d_out; a.mag = d_mag; a.win = p->win; a.tw1 = p->tw1; a.tw2 = p->tw2; a.tws = p->tws; a.twTop = p->twTop;
     a.pvRatio = ratio; a.pv = pv ? 1 : 0;
     a.c = (double)p->scale / (double)(p->F / 2);
     a.T = p->T; a.nFrames = p->nFrames; a.F = p->F; a.hop = p->hop; a.O = p->F / p->hop;
     a.nHops = (p->T + p->hop - 1) / p->hop;
     a.nRounds = (a.nHops + VP_STFT_WAVES - 1) / VP_STFT_WAVES;
     a.haloRounds = (a.O - 1 + VP_STFT_WAVES - 1) / VP_STFT_WAVES;
-    a.aligned = (p->T % 2 == 0 && p->hop % 2 == 0 && ((uintptr_t)d_in & 7) == 0) ? 1 : 0;
+    // (float2 loads per lane at 1024 points, float4 at 2048: rows and hops aligned to the load's width)
+    const int al = p->F == 2048 ? 4 : 2;
+    a.aligned = (p->T % al == 0 && p->hop % al == 0 && ((uintptr_t)d_in & (4 * al - 1)) == 0) ? 1 : 0;
     // runs: enough workgroups for two per CU (the kernel's register budget), but runs of at least four rounds per recomputed one;
     // the phase-vocoder stage carries a recurrence over the frames of a stream: one run
     int runs = 1;
@@ -1648,6 +1654,7 @@ extern "C" int vp_stft_roundtrip(vp_stft *p, const float *d_in, float *d_out, fl
 extern "C" int vp_stft_pitch_shift(vp_stft *p, const float *d_in, float *d_out, double semitones, void *hip_stream)
 {
     if (!p || !d_in || !d_out || !(semitones >= -12.0 && semitones <= 12.0)) return VP_ERR_INVALID_ARG;
+    if (p->F != 1024) return VP_ERR_GEOMETRY;                  // the phase-vocoder stage is built for 1024-point frames
     if (hipSetDevice(p->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     return stft_fused(p, d_in, d_out, nullptr, (hipStream_t)hip_stream, true, std::pow(2.0, semitones / 12.0));
 }

@@ -13,7 +13,8 @@ struct VpStftArgs {
     const double *win;                  // [F] sqrt-Hann (periodic), analysis = synthesis
     const double *tw1;                  // [64][8][2]  W_64^(m0 (lane >> 3))            second step of the 512-point transform
     const double *tw2;                  // [64][8][2]  W_512^(a lane)                    third step
-    const double *tws;                  // [64][4][2]  W_1024^(64 q + lane)              real-input split / merge
+    const double *tws;                  // [64][NP][2] W_(2F)^... real-input split / merge: W_F^(64 q + lane), NP = F / 256 pairs per lane
+    const double *twTop;                // [64][8][2]  W_1024^(64 q + lane): the radix-2 step on top of two 512-point transforms (F = 2048), else nullptr
     double pvRatio;                     // pitch ratio of the phase-vocoder stage
     double c;                           // scale / (F/2): overlap-add normalisation and the inverse transform's 1/N, folded into the merge
     int T, nFrames, nHops, nRounds;     // samples per stream; frames; hops of output (ceil(T / hop)); rounds of VP_STFT_WAVES frames

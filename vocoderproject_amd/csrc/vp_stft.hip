@@ -60,7 +60,27 @@ static size_t stft_pv_lds_bytes(int F)
 
 int vp_stft_supported(int F, int hop)
 {
-    return F == 1024 && hop > 0 && F % hop == 0 && F / hop >= 2 && F / hop <= 16;
+    return (F == 1024 || F == 2048) && hop > 0 && F % hop == 0 && F / hop >= 2 && F / hop <= 16;
+}
+
+// Overlap-add of one round, by the whole workgroup (behind the barrier that follows the wavefronts' slot writes): relative hop u of the
+// round (hops rd * NWV + u) takes frames w in [u - O + 1, u] IN FRAME ORDER on top of the carry of the hops the previous round left
+// incomplete; finished hops go to HBM (once), the others become the new carry.  slots: wavefront w's output frame at w * 2048 floats.
+__device__ __forceinline__ void stft_overlap_add(const VpStftArgs &A, const lds_f32 *slots, lds_f32 *carry, int s, int rd, bool emit, int tid)
+{
+    const int hop = A.hop, O = A.O, T = A.T;
+    float *o = A.out + (size_t)s * T;
+    for (int i = tid; i < hop; i += 64 * NWV) {
+        for (int u = 0; u < NWV + O - 1; u++) {
+            float v = (u < O - 1) ? carry[u * hop + i] : 0.f;
+            const int wlo = max(0, u - O + 1), whi = min(u, NWV - 1);
+            for (int w = wlo; w <= whi; w++) v += slots[w * 2048 + (u - w) * hop + i];
+            if (u < NWV) {
+                const long t = (long)(rd * NWV + u) * hop + i;
+                if (emit && t < T) o[t] = v;
+            } else carry[(u - NWV) * hop + i] = v;
+        }
+    }
 }
 
 #define VP_TWO_PI 6.283185307179586476925286766559
@@ -233,22 +253,107 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
             for (int r = 0; r < 8; r++) slot[lane + 64 * r] = f2{0.f, 0.f};
         }
         __syncthreads();
-        // ---- overlap-add: relative hop u of this round (hops rd * NWV + u) takes frames w in [u - O + 1, u] in frame order
-        {
-            const bool emit = rd >= rFirst;
-            float *o = A.out + (size_t)s * T;
-            for (int i = tid; i < hop; i += 64 * NWV) {
-                for (int u = 0; u < NWV + O - 1; u++) {
-                    float v = (u < O - 1) ? carry[u * hop + i] : 0.f;
-                    const int wlo = max(0, u - O + 1), whi = min(u, NWV - 1);
-                    for (int w = wlo; w <= whi; w++) v += slots[w * 2048 + (u - w) * hop + i];
-                    if (u < NWV) {
-                        const long t = (long)(rd * NWV + u) * hop + i;
-                        if (emit && t < T) o[t] = v;
-                    } else carry[(u - NWV) * hop + i] = v;
-                }
+        stft_overlap_add(A, slots, carry, s, rd, rd >= rFirst, tid);
+        __syncthreads();
+    }
+}
+
+// ---- 2048-point frames (BASELINE configs[4]'s "2048-pt FFT hop 512"): 1024 complex points, SIXTEEN per lane --------------------------
+// The same round structure; the transform is a radix-2 step on top of two 512-point ones.  Forward, decimation in time: the lane loads
+// z[2m] and z[2m + 1] for m = lane + 64 r (four consecutive samples: one aligned float4), E = FFT512(even), O = FFT512(odd),
+// Z[k'] = E + W^k' O, Z[k' + 512] = E - W^k' O (k' = 64 q + lane: in-lane, natural order).  Backward, decimation in frequency on the
+// conjugated spectrum: e = lo + hi, o = (lo - hi) W^k', two 512-point transforms, y[2k'] and y[2k' + 1] -- again four consecutive
+// samples per lane and register.  The 512-point transforms' twiddles come from LDS copies of the tables (the sixteen points, the eight
+// bin pairs and the top step's twiddles use the registers), the window from the global table (L1/L2-resident: 16 KB).
+template <bool MAG>
+__global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused2k(VpStftArgs A)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = blockIdx.y, run = blockIdx.x;
+    constexpr int N = 1024;                                                    // complex points = F / 2
+    const int F = A.F, hop = A.hop, T = A.T;
+    lds_d2 *xb = (lds_d2 *)smem + wv * 512;
+    lds_f32 *slots = (lds_f32 *)smem;                                          // slot w: the whole exchange buffer (2048 floats)
+    lds_f32 *carry = (lds_f32 *)smem + NWV * 2048;
+    lds_d2 *twL = (lds_d2 *)smem + stft_lds_base(F, hop) / 16;                 // [8][8] W_64 rows | [64][8] W_512
+    FftAddr L;
+    fft_addr_init(L, lane);
+    for (int i = tid; i < 64; i += 64 * NWV) twL[i] = ((const d2 *)A.tw1)[(i >> 3) * 64 + (i & 7)];
+    for (int i = tid; i < 512; i += 64 * NWV) twL[64 + i] = ((const d2 *)A.tw2)[i];
+    const lds_d2 *tw1p = twL + (lane >> 3) * 8, *tw2p = twL + 64 + lane * 8;
+    d2 wtop[8], ws[8];                                                         // W_1024^(64 q + lane), W_2048^(64 q + lane)
+#pragma unroll
+    for (int q = 0; q < 8; q++) { wtop[q] = ((const d2 *)A.twTop)[lane * 8 + q]; ws[q] = ((const d2 *)A.tws)[lane * 8 + q]; }
+    for (int i = tid; i < F - hop; i += 64 * NWV) carry[i] = 0.f;
+    __syncthreads();
+
+    const int rFirst = run * A.roundsPerRun;
+    const int r0 = max(0, rFirst - (run > 0 ? A.haloRounds : 0));
+    const int r1 = min(rFirst + A.roundsPerRun, A.nRounds);
+    const float *xs = A.in + (size_t)s * T;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) f4 lds_f4;
+    for (int rd = r0; rd < r1; rd++) {
+        const int f = rd * NWV + wv;
+        const bool live = f < A.nFrames;
+        lds_f4 *slot = (lds_f4 *)(slots + wv * 2048);
+        if (live) {
+            const float *x = xs + (size_t)f * hop;
+            C8 e, o;                                                           // even / odd packed points of the lane: z[2m], z[2m + 1], m = lane + 64 r
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int m = lane + 64 * r;
+                f4 v;
+                if (A.aligned) v = *(const f4 *)(x + 4 * m);
+                else v = f4{x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]};
+                const d2 w0 = ((const d2 *)A.win)[2 * m], w1 = ((const d2 *)A.win)[2 * m + 1];
+                e.re[r] = (double)v.x * w0.x; e.im[r] = (double)v.y * w0.y;
+                o.re[r] = (double)v.z * w1.x; o.im[r] = (double)v.w * w1.y;
             }
+            fft512(e, xb, L, tw1p, tw2p);
+            fft512(o, xb, L, tw1p, tw2p);
+            double hr[8], hi[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {                                      // radix-2 on top: lo = E + W^k' O (kept in e), hi = E - W^k' O
+                const double tr = __builtin_fma(o.re[q], wtop[q].x, -(o.im[q] * wtop[q].y)), ti = __builtin_fma(o.re[q], wtop[q].y, o.im[q] * wtop[q].x);
+                hr[q] = e.re[q] - tr; hi[q] = e.im[q] - ti;
+                e.re[q] += tr; e.im[q] += ti;
+            }
+            RPairsN<8> X;
+            rfft_split_n<8>(e.re, e.im, hr, hi, xb, lane, (const d2 *)ws, X);
+            if (MAG) {                                                         // |X[k]|, k <= N, natural order
+                float *mg = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int k = 64 * q + lane;
+                    mg[k] = (float)sqrt(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]);
+                    mg[N - k] = (float)sqrt(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]);
+                }
+                if (lane == 0) mg[N / 2] = (float)sqrt(X.hr * X.hr + X.hi * X.hi);
+            }
+            rfft_merge_conj_n<8>(e.re, e.im, hr, hi, xb, lane, (const d2 *)ws, X, A.c);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {                                      // radix-2 on top, decimation in frequency: e = lo + hi, o = (lo - hi) W^k'
+                const double dr = e.re[q] - hr[q], di = e.im[q] - hi[q];
+                e.re[q] += hr[q]; e.im[q] += hi[q];
+                o.re[q] = __builtin_fma(dr, wtop[q].x, -(di * wtop[q].y)); o.im[q] = __builtin_fma(dr, wtop[q].y, di * wtop[q].x);
+            }
+            fft512(e, xb, L, tw1p, tw2p);                                      // y[2k'] ...
+            fft512(o, xb, L, tw1p, tw2p);                                      // ... and y[2k' + 1], k' = lane + 64 r: x'[2n] = Re y[n], x'[2n + 1] = -Im y[n]
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int m = lane + 64 * r;
+                const d2 w0 = ((const d2 *)A.win)[2 * m], w1 = ((const d2 *)A.win)[2 * m + 1];
+                slot[m] = f4{(float)(e.re[r] * w0.x), (float)(-(e.im[r] * w0.y)), (float)(o.re[r] * w1.x), (float)(-(o.im[r] * w1.y))};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) slot[lane + 64 * r] = f4{0.f, 0.f, 0.f, 0.f};
         }
+        __syncthreads();
+        stft_overlap_add(A, slots, carry, s, rd, rd >= rFirst, tid);
         __syncthreads();
     }
 }
@@ -262,7 +367,11 @@ hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStrea
     }
     const size_t lds = vp_stft_lds_bytes(a.F, a.hop);
     const dim3 grid(nRuns, nStreams), block(64 * NWV);
-    if (a.pv)
+    if (a.F == 2048) {
+        const size_t lds2 = lds + (64 + 512) * 16;                             // + the LDS copies of the 512-point transform's twiddle tables
+        if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused2k<true>), grid, block, lds2, st, a);
+        else hipLaunchKernelGGL((vp_k_stft_fused2k<false>), grid, block, lds2, st, a);
+    } else if (a.pv)
         hipLaunchKernelGGL((vp_k_stft_fused<true, false>), grid, block, lds + stft_pv_lds_bytes(a.F), st, a);
     else if (a.mag)
         hipLaunchKernelGGL((vp_k_stft_fused<false, true>), grid, block, lds, st, a);
