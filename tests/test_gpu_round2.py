@@ -247,13 +247,17 @@ def test_stft_geometry_validation_and_largest_frame():
     with pytest.raises(VpError) as e:
         StftRoundTrip(2, 4096, 1024, 1024)                           # hop == frame: no overlap to normalise
     assert e.value.code == -4
-    T = 4096 * 6
-    st = StftRoundTrip(2, T, 4096, 1024)                              # 96 KB of dynamic LDS
+    with pytest.raises(VpError) as e:
+        StftRoundTrip(2, 4096 * 6, 4096, 1024)                       # round 4: the fused kernels are built for 1024 and 2048 points
+    assert e.value.code == -4
+    T = 2048 * 6
+    st = StftRoundTrip(2, T, 2048, 512)                               # the largest frame: sixteen complex points per lane
+    assert st.fused
     x = torch.randn((2, T), dtype=torch.float32, device="cuda") * 0.1
     y = torch.empty_like(x)
     st(x, y)
     torch.cuda.synchronize()
-    a, b = x.cpu().numpy()[:, 4096:-4096], y.cpu().numpy()[:, 4096:-4096]
+    a, b = x.cpu().numpy()[:, 2048:-2048], y.cpu().numpy()[:, 2048:-2048]
     assert np.abs(a - b).max() < 1e-5
 
 

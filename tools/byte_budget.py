@@ -24,13 +24,13 @@ def stage_bytes(S, N, W, hop, oV, oS, F, C):
         "vp_k_v2_autocorr": ((2 * S * (N + W) * 4 + nw * (oV + 1 + oS + 1) * 8) / MB,
                              "every staged sample of the block's windows once (f32), r[] out (f64)"),
         "vp_k_v2_levinson2": ((2 * nw * (oV + 1 + oS + 1) * 8) / MB, "r[] in, a[] out (f64)"),
-        "vp_k_v2_fir2": ((2 * S * (N + W) * 4 + nw * (oV + 1 + oS + 1) * 8 + nw * W * 8 + nw * 2 * 8) / MB,
-                         "staged samples once, a[] in, the carrier's residual of every window out (f64 [W] per window: windows overlap W/hop times), energies"),
+        "vp_k_v2_fir2": ((2 * S * (N + W) * 4 + nw * (oV + 1 + oS + 1) * 8 + nw * W * 4 + nw * 2 * 8) / MB,
+                         "staged samples once, a[] in, the carrier's residual of every window out (f32 [W] per window in FAST mode: windows overlap W/hop times), energies"),
         "vp_k_v2_energy": ((nw * 4 * 8) / MB, "partial energies in, window energies out"),
-        "vp_k_v2_iir_fast": ((2 * nw * W * 8 + nw * (oV + 1) * 8) / MB, "residual in, a[] in, the window's all-pole output out (f64 [W] per window)"),
+        "vp_k_v2_iir_fast": ((2 * nw * W * 4 + nw * (oV + 1) * 8) / MB, "residual in, a[] in, the window's all-pole output out (both f32 [W] per window, round 4)"),
         "vp_k_v2_iir_exact": ((2 * nw * W * 8 + nw * (oV + 1) * 8) / MB, "residual in, a[] in, the window's all-pole output out (f64 [W] per window)"),
-        "vp_k_v2_ola": ((nw * W * 8 + 2 * S * N * 8 + S * 2 * N * 4) / MB,
-                        "every window's output in once, the accumulator's block slice read and written (f64), the block's output out (f32) when it emits"),
+        "vp_k_v2_ola": ((nw * W * 4 + 2 * S * N * 8 + S * 2 * N * 4) / MB,
+                        "every window's output in once (f32 in FAST mode), the accumulator's block slice read and written (f64), the block's output out (f32) when it emits"),
         "vp_k_pitch": ((S * N * 4 * 2 + S * 2 * N * 4 + S * 2 * 2048) / MB,
                        "voice in (slab + ring write), output out (f32), tracker state in and out -- the frame in flight would not have to leave the chip"),
     }

@@ -56,6 +56,9 @@ __device__ __forceinline__ V2Col v2_col(double *arr, int K, int w) { V2Col r; r.
 //   xT[ch][G][i / 4][lane][4]  f32   sample i of window 64 G + lane (every window materialised, overlap and all)
 //   eT[ch][G][i / 2][lane][2]  f64   residuals
 // (ch 0 voice, 1 side chain.)  The all-pole output goes to out[w][i], window-major, which is what the overlap-add reads.
+// VP_IIR_FAST (round 4) keeps the two intermediates that only its own kernels read in f32, in the same buffers: the side chain's residual
+// as eF[G][i / 4][lane][4] (the voice's is not stored at all in that mode) and the all-pole output as outF[w][i] -- half the bytes written
+// by the residual and recursion kernels and read by the recursion and the overlap-add (the arithmetic stays double; tolerance mode).
 struct V2X {                                                                // samples of one window, by index
     const float *base; int stride;                                         // base: (G, 0, lane, 0)
     __device__ __forceinline__ float operator[](int i) const { return base[(size_t)(i >> 2) * 256 + (i & 3)]; }
@@ -75,6 +78,17 @@ __device__ __forceinline__ V2ET<double> v2_e(const VpV2 &v, int ch, int w)
 {
     V2ET<double> r;
     r.base = v.eT + (((size_t)ch * v.nGroupsMax + (w >> 6)) * v.W2p * 64 + (w & 63)) * 2;
+    return r;
+}
+
+struct V2EF {                                                               // f32 residuals of one window (VP_IIR_FAST), by index
+    float *base;
+    __device__ __forceinline__ float &operator[](int i) const { return base[(size_t)(i >> 2) * 256 + (i & 3)]; }
+};
+__device__ __forceinline__ V2EF v2_ef(const VpV2 &v, int w)
+{
+    V2EF r;
+    r.base = (float *)v.eT + (((size_t)(w >> 6)) * v.W4p * 64 + (w & 63)) * 4;
     return r;
 }
 
@@ -323,7 +337,8 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
     const V2X x = v2_x(v, isS ? 1 : 0, wc);
     const V2Col ag = isS ? v2_col(v.aS, V2_RS_STRIDE, wc) : v2_col(v.aV, V2_RV_STRIDE, wc);
     const V2ET<double> e = v2_e(v, isS ? 1 : 0, wc);
-    const bool store = q.live && (isS || !c.iirFast);
+    const V2EF ef = v2_ef(v, wc);
+    const bool store = q.live && (isS || !c.iirFast), storeF = c.iirFast;
     // the slice's stretch of the window function in LDS, wl[k] = win[i0 - P + k] (uniform reads: see vp_k_v2_autocorr)
     lds_f64 *wl = (lds_f64 *)smem + P - i0;                                 // wl[i] = win[i] for i in [i0 - P, i1 + 8)
     for (int k = lane; k < P + V2_FIR_SLICE + 8; k += WAVE) { const int i = i0 - P + k; ((lds_f64 *)smem)[k] = (i >= 0 && i < W) ? d.vocWin[i] : 0.0; }
@@ -354,8 +369,9 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
         _Pragma("unroll") for (int t = P - 1; t >= 4; t--) h[t] = h[t - 4]; \
         h[3] = xn[0]; h[2] = xn[1]; h[1] = xn[2]; h[0] = xn[3]; \
         _Pragma("unroll") for (int t = 0; t < 4; t++) Ep += en[t] * en[t]; \
-        if (store) { typedef double d2_ __attribute__((ext_vector_type(2))); d2_ p0_, p1_; p0_.x = en[0]; p0_.y = en[1]; p1_.x = en[2]; p1_.y = en[3]; \
-                     *(d2_ *)&e.base[(size_t)((I) >> 1) * 128] = p0_; *(d2_ *)&e.base[(size_t)(((I) >> 1) + 1) * 128] = p1_; } }
+        if (store) { if (storeF) *(float4 *)&ef.base[(size_t)((I) >> 2) * 256] = make_float4((float)en[0], (float)en[1], (float)en[2], (float)en[3]); \
+                     else { typedef double d2_ __attribute__((ext_vector_type(2))); d2_ p0_, p1_; p0_.x = en[0]; p0_.y = en[1]; p1_.x = en[2]; p1_.y = en[3]; \
+                     *(d2_ *)&e.base[(size_t)((I) >> 1) * 128] = p0_; *(d2_ *)&e.base[(size_t)(((I) >> 1) + 1) * 128] = p1_; } } }
     // (loads run one trip ahead and are unconditional: past the window they land in the tile's padding)
     V2_FIR_LOAD(fa, i0)
     int i = i0;
@@ -378,7 +394,7 @@ __device__ __forceinline__ void v2_fir_body(const VpGeom &g, const VpCall &c, co
         for (int t = P - 1; t >= 1; t--) h[t] = h[t - 1];
         h[0] = xn;
         Ep += acc * acc;
-        if (store) e[i] = acc;
+        if (store) { if (storeF) ef[i] = (float)acc; else e[i] = acc; }
     }
     if (q.live) v.EEp[((size_t)wc * 2 + (isS ? 1 : 0)) * v.nSlices + blockIdx.y] = Ep;
 }
@@ -525,8 +541,8 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
     const double one = 1.0, zero = 0.0;
     bool live[NI], any = false;
     double gg[NI], na[NI][T], st[NI][T];
-    V2ET<double> es[NI];
-    double *out[NI];
+    V2EF es[NI];
+    float *out[NI];
 #pragma unroll
     for (int k = 0; k < NI; k++) {
         const int w = (blockIdx.x * 4 + (lane >> 4)) * NI + k;
@@ -534,8 +550,8 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
         const int wc = q.b * c.nWin + q.j;
         live[k] = q.live;
         any = any || q.live;
-        es[k] = v2_e(v, 1, wc);
-        out[k] = v.out + (size_t)wc * W;
+        es[k] = v2_ef(v, wc);
+        out[k] = (float *)v.out + (size_t)wc * W;
         gg[k] = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
         const V2Col ag = v2_col(v.aV, V2_RV_STRIDE, wc);
 #pragma unroll
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
     // (g x for the sixteen samples of a trip is taken first, off the recursion's critical path: per sample the chain is
     // then  s_1 broadcast-add -> state update  and nothing else)
 #define V2_IF_GX(X, GX, G) { _Pragma("unroll") for (int u_ = 0; u_ < 16; u_++) GX[u_] = zero * zero; \
-        double xx_ = X; asm volatile("s_nop 1" : "+v"(xx_)); \
+        double xx_ = (double)(X); asm volatile("s_nop 1" : "+v"(xx_)); \
         VP_FMAC_BCAST(GX[0], xx_, G, 0); VP_FMAC_BCAST(GX[1], xx_, G, 1); VP_FMAC_BCAST(GX[2], xx_, G, 2); VP_FMAC_BCAST(GX[3], xx_, G, 3); \
         VP_FMAC_BCAST(GX[4], xx_, G, 4); VP_FMAC_BCAST(GX[5], xx_, G, 5); VP_FMAC_BCAST(GX[6], xx_, G, 6); VP_FMAC_BCAST(GX[7], xx_, G, 7); \
         VP_FMAC_BCAST(GX[8], xx_, G, 8); VP_FMAC_BCAST(GX[9], xx_, G, 9); VP_FMAC_BCAST(GX[10], xx_, G, 10); VP_FMAC_BCAST(GX[11], xx_, G, 11); \
@@ -568,16 +584,17 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
 #define V2_IF_TRIP(X, I) { double yo_[NI], gx_[NI][16]; \
         _Pragma("unroll") for (int k = 0; k < NI; k++) { yo_[k] = 0.0; V2_IF_GX(X[k], gx_[k], gg[k]) } \
         V2_IF_STEPS \
-        _Pragma("unroll") for (int k = 0; k < NI; k++) if (live[k]) out[k][(I) + m] = yo_[k]; }
+        _Pragma("unroll") for (int k = 0; k < NI; k++) if (live[k]) out[k][(I) + m] = (float)yo_[k]; }
     const int W16 = W & ~15;
     // (round 3) the trip's one load is requested THREE trips ahead (four named registers): a trip is 16 samples x ~44 issue cycles,
     // 0.3 us -- with one wavefront per SIMD (few, long windows) or two, one trip of lead did not cover a round trip to memory
     // (the residuals of a block are tens of megabytes: they do not come from L2), and the recursion sat out the difference
-    double xa[NI], xb[NI], xc[NI], xd[NI];
+    // (held as loaded -- f32 -- and widened where the trip consumes them: a conversion right behind the load would wait for it)
+    float xa[NI], xb[NI], xc[NI], xd[NI];
 #pragma unroll
     for (int k = 0; k < NI; k++) {
-        xa[k] = (W16 > 0) ? es[k][m] : 0.0; xb[k] = (W16 > 16) ? es[k][16 + m] : 0.0;
-        xc[k] = (W16 > 32) ? es[k][32 + m] : 0.0; xd[k] = (W16 > 48) ? es[k][48 + m] : 0.0;
+        xa[k] = (W16 > 0) ? es[k][m] : 0.0f; xb[k] = (W16 > 16) ? es[k][16 + m] : 0.0f;
+        xc[k] = (W16 > 32) ? es[k][32 + m] : 0.0f; xd[k] = (W16 > 48) ? es[k][48 + m] : 0.0f;
     }
 #define V2_IF_NEXT(X, I) if ((I) < W16) { _Pragma("unroll") for (int k = 0; k < NI; k++) X[k] = es[k][(I) + m]; }
     for (int i = 0; i < W16; i += 64) {
@@ -589,12 +606,12 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
     }
 #undef V2_IF_NEXT
     if (W16 < W) {                                                          // the ragged end: same steps, masked loads and stores
-        double xr[NI], yo_[NI], gx_[NI][16];
+        float xr[NI]; double yo_[NI], gx_[NI][16];
 #pragma unroll
-        for (int k = 0; k < NI; k++) { xr[k] = (W16 + m < W) ? es[k][W16 + m] : 0.0; yo_[k] = 0.0; V2_IF_GX(xr[k], gx_[k], gg[k]) }
+        for (int k = 0; k < NI; k++) { xr[k] = (W16 + m < W) ? es[k][W16 + m] : 0.0f; yo_[k] = 0.0; V2_IF_GX(xr[k], gx_[k], gg[k]) }
         V2_IF_STEPS
 #pragma unroll
-        for (int k = 0; k < NI; k++) if (live[k] && W16 + m < W) out[k][W16 + m] = yo_[k];
+        for (int k = 0; k < NI; k++) if (live[k] && W16 + m < W) out[k][W16 + m] = (float)yo_[k];
     }
 #undef V2_IF_GX
 #undef V2_IF_STEPS
@@ -616,19 +633,21 @@ __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, 
             d.EeArr[(size_t)s * 20 + tid] = hnew;
         }
         const double gainVoc = d.pitch[s].sp.gainVoc;
-        const double *o = v.out + (size_t)b * c.nWin * g.W;
+        const size_t o0 = (size_t)b * c.nWin * g.W;
         double *acc = d.outAcc + (size_t)s * g.outSize;
         const int W = g.W, span = (c.nWin - 1) * g.h + W;
+        auto run = [&](auto *o) {                                             // (o: the block's windows, f32 in VP_IIR_FAST mode, else f64)
         for (int t = tid; t < span; t += blockDim.x) {
             int pos = (c.outCounter + c.vStart + t) % g.outSize;
             double a = acc[pos];
             const int jlo = max(0, (t - W + g.h) / g.h), jhi = min(c.nWin - 1, t / g.h);
             for (int j = jlo; j <= jhi; j++) {
                 const int i = t - j * g.h;
-                if (i >= 0 && i < W) a += gainVoc * o[(size_t)j * W + i] * d.vocWin[i];
+                if (i >= 0 && i < W) a += gainVoc * (double)o[(size_t)j * W + i] * d.vocWin[i];
             }
             acc[pos] = a;
-        }
+        } };
+        if (c.iirFast) run((const float *)v.out + o0); else run((const double *)v.out + o0);
     }
     if (c.fuseEmit) {
         __syncthreads();
@@ -722,7 +741,9 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
     const double gainVoc = sp.gainVoc;
     double *acc = d.outAcc + (size_t)s * g.outSize;
     double *acc2 = d.outAcc2 ? d.outAcc2 + (size_t)s * g.outSize : nullptr;
-    const double *o = v.out + (size_t)wBase * W;
+    const bool fastF = c.iirFast != 0;                                      // the all-pole output is f32 in VP_IIR_FAST mode
+    const float *oF = (const float *)v.out + (size_t)wBase * W;
+    const double *oD = v.out + (size_t)wBase * W;
     double *pl = d.pLin ? d.pLin + (size_t)s * ((size_t)V2_MB_MAX * g.N + g.outSize) : nullptr;
     for (int t = tid; t < BN + g.outSize; t += blockDim.x) {
         double val = 0.0;
@@ -735,7 +756,7 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
             const int klo = max(0, (t - v0 - W + g.h) / g.h), khi = min(NWs - 1, (t - v0) / g.h);
             for (int k = klo; k <= khi; k++) {
                 const int i = t - v0 - k * g.h;
-                if (i >= 0 && i < W && v.meta[wBase + k].x) val += gainVoc * o[(size_t)k * W + i] * d.vocWin[i];
+                if (i >= 0 && i < W && v.meta[wBase + k].x) val += gainVoc * (fastF ? (double)oF[(size_t)k * W + i] : oD[(size_t)k * W + i]) * d.vocWin[i];
             }
         }
         if (pl) { val += pl[t]; pl[t] = 0.0; }                               // the pitch corrector's chunks of this call (and the slot cleared for the next)
