@@ -42,6 +42,20 @@ def test_no_scratch_in_the_kernels_the_baseline_configs_launch(resources):
     assert not bad, f"kernels with scratch (bytes per lane): {bad}"
 
 
+def test_scratch_of_every_product_kernel(resources):
+    """Round 4: every kernel of the product library is free of scratch except the ones listed here with their ceilings -- the exact
+    multi-block general build, the register-light GENERAL-geometry builds (128 registers; the common-case build the BASELINE configs
+    launch has none) and the order-48 workgroup vocoder (never launched by a BASELINE config: the pipeline takes its batches).
+    What was removed in round 4 were uniform values the compiler computed on the vector ALU once per kernel and then carried
+    (an integer modulo by a run-time value, (double) of the frame length, the constant 1.0 of the DPP forms): DESIGN.md section 4.12."""
+    allowed = {"vp_k_pitch_multi": 36, "vp_k_pitch_lite": 16, "vp_k_pitch_lite_fast": 32, "vp_k_pitch_lite_fast_multi": 64,
+               "vp_k_pitch_lite_fast_multi_c": 48, "vp_k_vocoder_o48": 444}
+    bad = {k: r["scratch"] for k, r in resources.items() if r["scratch"] > allowed.get(k, 0)}
+    assert not bad, f"scratch bytes per lane above the ceilings: {bad}"
+    for k in ("vp_k_pitch", "vp_k_pitch_fast", "vp_k_pitch_fast_multi", "vp_k_pitch_c", "vp_k_pitch_fast_c", "vp_k_pitch_fast_multi_c", "vp_k_pitch_lite_fast_c"):
+        assert resources[k]["scratch"] == 0, (k, resources[k])
+
+
 def test_occupancy_two_for_the_full_register_builds(resources):
     """512-thread workgroups need two wavefronts per SIMD: VGPRs + AGPRs must stay within 256."""
     for k in ("vp_k_pitch_fast_c", "vp_k_pitch_c", "vp_k_pitch_fast", "vp_k_vocoder", "vp_k_vocoder_o48"):

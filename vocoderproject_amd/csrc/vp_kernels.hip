@@ -149,6 +149,23 @@ __device__ __forceinline__ int vp_tid()
     return t;
 }
 
+// (double)v of a wave-uniform integer, converted where it is used: the compiler otherwise converts once at the top of the kernel and
+// carries the pair of vector registers through every phase (the register-light builds spilled it)
+__device__ __forceinline__ double vp_f64_here(int v)
+{
+    asm volatile("" : "+s"(v));
+    return (double)v;
+}
+
+// 1.0 in a vector register pair for the DPP forms (their operands cannot be inline constants), made where the routine starts: a plain
+// `const double one = 1.0` is hoisted to the top of the kernel and kept alive -- or spilled -- across every phase
+__device__ __forceinline__ double vp_one()
+{
+    double o;
+    asm volatile("v_mov_b64 %0, 1.0" : "=v"(o));
+    return o;
+}
+
 // the stream this workgroup serves (see VpDev::streamMap)
 __device__ __forceinline__ int vp_stream(const VpDev &d)
 {
@@ -242,7 +259,7 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
         const float *ring = tid == 0 ? vr : sr0;
         double T = 0.0;
         for (int w = 0; w < nt / WAVE; w++) T += red[tid][w];
-        const double band = T * (double)(2 * g.inSize + 64) * 1.1102230246251565e-16 * 1.5;
+        const double band = T * vp_f64_here(2 * g.inSize + 64) * 1.1102230246251565e-16 * 1.5;
         int open;
         if (T - g.gateThrSum > band) open = 1;
         else if (g.gateThrSum - T > band) open = 0;
