@@ -292,6 +292,15 @@ int vp_stft_is_fused(const vp_stft *p);                      /* 1 (every handle 
 /* Diagnostic: cut every stream into this many runs of frames (one workgroup each) instead of choosing from the batch size
  * (0 = automatic).  The output does not depend on it (tests). */
 int vp_stft_set_runs(vp_stft *p, int runs_per_stream);
+/* Arithmetic of vp_stft_roundtrip's transforms.  VP_STFT_F64 (default): double, as everything else in this library.  VP_STFT_F32: the
+ * transform, split and merge in single precision (vp_k_stft_fused32: an f32 vector instruction issues in half the cycles of an fp64 one,
+ * the kernel needs half the registers and half the LDS bytes) -- input and output are float32 either way; the result differs from the
+ * default's by rounding (~2e-7 of the signal's scale; the north_star's bound is 1e-4 RMS).  1024-point frames only (VP_ERR_GEOMETRY
+ * otherwise); vp_stft_pitch_shift always runs in double (its phases accumulate over the whole stream). */
+#define VP_STFT_F64 0
+#define VP_STFT_F32 1
+int vp_stft_set_precision(vp_stft *p, int precision);
+int vp_stft_get_precision(const vp_stft *p);
 
 const char *vp_error_string(int code);
 const char *vp_last_error(const vp_handle *h);

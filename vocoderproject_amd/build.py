@@ -20,7 +20,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libvp_amd.so")
 SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_stft.hip", "vp_capi.hip"]
 PARTS = ["vp_fft.inc", "vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc"]      # included by vp_kernels.hip
-DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h", "vp_stft.h"]
+DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h", "vp_stft.h", "vp_fft32.inc"]
 ARCH = "gfx950"
 NUM_TUS = 5          # groups of kernels in vp_kernels.hip (VP_TU)
 
@@ -95,7 +95,7 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             hsh = hashlib.sha256((hipcc_version() + " ".join(cmd[:-1]).replace(tmp, "")).encode())
             deps = {"vp_kernels.hip": ["vp_kernels.hip", "vp_common.h"] + PARTS,
                     "vp_voc2.hip": ["vp_voc2.hip", "vp_voc2.h", "vp_kernels.hip", "vp_common.h"] + PARTS,
-                    "vp_stft.hip": ["vp_stft.hip", "vp_stft.h", "vp_fft.inc"]}.get(os.path.basename(src))
+                    "vp_stft.hip": ["vp_stft.hip", "vp_stft.h", "vp_fft.inc", "vp_fft32.inc"]}.get(os.path.basename(src))
             if deps is None:
                 deps = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.basename(src), os.path.join(ROOT, "include", "vp_amd.h")]
             for dep in deps:

@@ -1547,6 +1547,7 @@ struct vp_stft {
     double *win = nullptr, *tw1 = nullptr, *tw2 = nullptr, *tws = nullptr, *twTop = nullptr;
     float scale;
     int runsPerStream = 0;            // 0: chosen from the batch so that the grid fills the chip; > 0: vp_stft_set_runs (tests)
+    int f32 = 0;                      // vp_stft_set_precision
 };
 
 static void stft_free(vp_stft *p)
@@ -1616,12 +1617,22 @@ extern "C" int vp_stft_set_runs(vp_stft *p, int runs_per_stream)
     return VP_OK;
 }
 
+extern "C" int vp_stft_set_precision(vp_stft *p, int precision)
+{
+    if (!p || (precision != VP_STFT_F64 && precision != VP_STFT_F32)) return VP_ERR_INVALID_ARG;
+    if (precision == VP_STFT_F32 && p->F != 1024) return VP_ERR_GEOMETRY;       // the single-precision kernel is built for 1024-point frames
+    p->f32 = precision == VP_STFT_F32;
+    return VP_OK;
+}
+extern "C" int vp_stft_get_precision(const vp_stft *p) { return p ? (p->f32 ? VP_STFT_F32 : VP_STFT_F64) : VP_ERR_INVALID_ARG; }
+
 static int stft_fused(vp_stft *p, const float *d_in, float *d_out, float *d_mag, hipStream_t st, bool pv, double ratio)
 {
     VpStftArgs a;
     memset(&a, 0, sizeof a);
     a.in = d_in; a.out = d_out; a.mag = d_mag; a.win = p->win; a.tw1 = p->tw1; a.tw2 = p->tw2; a.tws = p->tws; a.twTop = p->twTop;
     a.pvRatio = ratio; a.pv = pv ? 1 : 0;
+    a.f32 = (p->f32 && !pv) ? 1 : 0;                           // (the phase-vocoder stage keeps double: its phases accumulate over the stream)
     a.c = (double)p->scale / (double)(p->F / 2);
     a.T = p->T; a.nFrames = p->nFrames; a.F = p->F; a.hop = p->hop; a.O = p->F / p->hop;
     a.nHops = (p->T + p->hop - 1) / p->hop;
@@ -1634,7 +1645,8 @@ static int stft_fused(vp_stft *p, const float *d_in, float *d_out, float *d_mag,
     // the phase-vocoder stage carries a recurrence over the frames of a stream: one run
     int runs = 1;
     if (!pv) {
-        runs = p->runsPerStream > 0 ? p->runsPerStream : (2 * 256 + p->S - 1) / p->S;
+        // (four workgroups per CU in the single-precision build: half the registers)
+        runs = p->runsPerStream > 0 ? p->runsPerStream : ((a.f32 ? 4 : 2) * 256 + p->S - 1) / p->S;
         runs = std::max(1, std::min(runs, a.nRounds / (4 * a.haloRounds)));
     }
     a.roundsPerRun = (a.nRounds + runs - 1) / runs;

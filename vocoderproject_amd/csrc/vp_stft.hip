@@ -44,13 +44,14 @@
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) double lds_f64;
 #include "vp_fft.inc"
+#include "vp_fft32.inc"
 
-// exchange buffers / output slots, overlap-add carry (F - hop floats), rounded up to 16 bytes
-__host__ __device__ static inline size_t stft_lds_base(int F, int hop)
+// exchange buffers / output slots (8 KB per wavefront; 4 KB in the single-precision build), overlap-add carry (F - hop floats), rounded up to 16 bytes
+__host__ __device__ static inline size_t stft_lds_base(int F, int hop, int f32 = 0)
 {
-    return (((size_t)NWV * 8192 + (size_t)(F - hop) * sizeof(float)) + 15) & ~(size_t)15;
+    return (((size_t)NWV * (f32 ? 4096 : 8192) + (size_t)(F - hop) * sizeof(float)) + 15) & ~(size_t)15;
 }
-size_t vp_stft_lds_bytes(int F, int hop) { return stft_lds_base(F, hop); }
+size_t vp_stft_lds_bytes(int F, int hop, int f32) { return stft_lds_base(F, hop, f32); }
 static size_t stft_pv_lds_bytes(int F)
 {
     const size_t nb = (size_t)F / 2 + 1;
@@ -65,7 +66,8 @@ int vp_stft_supported(int F, int hop)
 
 // Overlap-add of one round, by the whole workgroup (behind the barrier that follows the wavefronts' slot writes): relative hop u of the
 // round (hops rd * NWV + u) takes frames w in [u - O + 1, u] IN FRAME ORDER on top of the carry of the hops the previous round left
-// incomplete; finished hops go to HBM (once), the others become the new carry.  slots: wavefront w's output frame at w * 2048 floats.
+// incomplete; finished hops go to HBM (once), the others become the new carry.  slots: wavefront w's output frame at w * SLOT floats.
+template <int SLOT = 2048>
 __device__ __forceinline__ void stft_overlap_add(const VpStftArgs &A, const lds_f32 *slots, lds_f32 *carry, int s, int rd, bool emit, int tid)
 {
     const int hop = A.hop, O = A.O, T = A.T;
@@ -74,7 +76,7 @@ __device__ __forceinline__ void stft_overlap_add(const VpStftArgs &A, const lds_
         for (int u = 0; u < NWV + O - 1; u++) {
             float v = (u < O - 1) ? carry[u * hop + i] : 0.f;
             const int wlo = max(0, u - O + 1), whi = min(u, NWV - 1);
-            for (int w = wlo; w <= whi; w++) v += slots[w * 2048 + (u - w) * hop + i];
+            for (int w = wlo; w <= whi; w++) v += slots[w * SLOT + (u - w) * hop + i];
             if (u < NWV) {
                 const long t = (long)(rd * NWV + u) * hop + i;
                 if (emit && t < T) o[t] = v;
@@ -358,6 +360,90 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused2k(VpStftArgs A)
     }
 }
 
+// ---- single precision (vp_stft_set_precision(t, VP_STFT_F32); 1024-point frames) ------------------------------------------------------
+// The same kernel with the transform, split and merge in f32 (vp_fft32.inc).  Why it is a build of its own and not the default: the fp64
+// kernel is bound by its instruction stream -- 613 fp64 vector instructions per lane and frame at 4 cycles each, two wavefronts per SIMD
+// (223 registers) -- and an f32 vector instruction issues in 2 cycles once two wavefronts share the SIMD (MI355X_MICROARCH.md,
+// "vector-instruction ISSUE cost"); it also needs half the registers (four wavefronts per SIMD instead of two) and half the LDS
+// bytes per exchange.  The input is f32 and the output is f32 either way; what changes is the rounding inside: ~1e-7 relative per
+// frame instead of ~1e-16, two orders below the 1e-4 the north_star allows -- but not the bit pattern of the default build, hence opt-in.
+template <bool MAG>
+__global__ __launch_bounds__(64 * NWV, 4) void vp_k_stft_fused32(VpStftArgs A)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = blockIdx.y, run = blockIdx.x;
+    constexpr int N = 512;
+    const int F = A.F, hop = A.hop, T = A.T;
+    lds_f2 *xb = (lds_f2 *)smem + wv * 512;                                    // the wavefront's exchange buffer (4 KB) = its output slot (F floats)
+    lds_f32 *slots = (lds_f32 *)smem;
+    lds_f32 *carry = (lds_f32 *)smem + NWV * 1024;
+    Fft32Addr L;
+    fft32_addr_init(L, lane);
+    // the double-precision tables, rounded once: the second step's twiddles (a row of eight per lane >> 3: 64 values) in LDS, the rest in registers
+    lds_f2 *tw1L = (lds_f2 *)((lds_f32 *)smem + stft_lds_base(F, hop, 1) / 4);
+    if (tid < 64) { const d2 t = ((const d2 *)A.tw1)[(tid >> 3) * 64 + (tid & 7)]; tw1L[tid] = f2{(float)t.x, (float)t.y}; }
+    const lds_f2 *tw1 = tw1L + (lane >> 3) * 8;
+    f2 tw2[8], wa[8], ws[4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const d2 t2 = ((const d2 *)A.tw2)[lane * 8 + r], w = ((const d2 *)A.win)[lane + 64 * r];
+        tw2[r] = f2{(float)t2.x, (float)t2.y}; wa[r] = f2{(float)w.x, (float)w.y};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const d2 t = ((const d2 *)A.tws)[lane * 4 + q]; ws[q] = f2{(float)t.x, (float)t.y}; }
+    const float c = (float)A.c;
+    for (int i = tid; i < F - hop; i += 64 * NWV) carry[i] = 0.f;
+    __syncthreads();
+
+    const int rFirst = run * A.roundsPerRun;
+    const int r0 = max(0, rFirst - (run > 0 ? A.haloRounds : 0));
+    const int r1 = min(rFirst + A.roundsPerRun, A.nRounds);
+    const float *xs = A.in + (size_t)s * T;
+    for (int rd = r0; rd < r1; rd++) {
+        const int f = rd * NWV + wv;
+        const bool live = f < A.nFrames;
+        if (live) {
+            const float *x = xs + (size_t)f * hop;
+            C8f z;
+            f2 xv[8];
+            if (A.aligned) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) xv[r] = *(const f2 *)(x + 2 * (lane + 64 * r));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) xv[r] = f2{x[2 * (lane + 64 * r)], x[2 * (lane + 64 * r) + 1]};
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) { z.re[r] = xv[r].x * wa[r].x; z.im[r] = xv[r].y * wa[r].y; }
+            fft512f(z, xb, L, tw1, (const f2 *)tw2);
+            RPairsT<float, 4> X;
+            rfft_split_n<4>(z.re, z.im, z.re + 4, z.im + 4, xb, lane, (const f2 *)ws, X);
+            if (MAG) {
+                float *m = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = 64 * q + lane;
+                    m[k] = sqrtf(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]);
+                    m[N - k] = sqrtf(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]);
+                }
+                if (lane == 0) m[N / 2] = sqrtf(X.hr * X.hr + X.hi * X.hi);
+            }
+            rfft_merge_conj_n<4>(z.re, z.im, z.re + 4, z.im + 4, xb, lane, (const f2 *)ws, X, c);
+            fft512f(z, xb, L, tw1, (const f2 *)tw2);
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; r++) xb[lane + 64 * r] = f2{z.re[r] * wa[r].x, -(z.im[r] * wa[r].y)};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) xb[lane + 64 * r] = f2{0.f, 0.f};
+        }
+        __syncthreads();
+        stft_overlap_add<1024>(A, slots, carry, s, rd, rd >= rFirst, tid);
+        __syncthreads();
+    }
+}
+
 hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStream_t st)
 {
     static bool attr = false;
@@ -365,9 +451,13 @@ hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStrea
         (void)hipFuncSetAttribute((const void *)vp_k_stft_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         attr = true;
     }
-    const size_t lds = vp_stft_lds_bytes(a.F, a.hop);
+    const size_t lds = vp_stft_lds_bytes(a.F, a.hop, a.f32);
     const dim3 grid(nRuns, nStreams), block(64 * NWV);
-    if (a.F == 2048) {
+    if (a.f32) {
+        const size_t lds32 = lds + 64 * 8;                                      // + the second step's twiddle rows
+        if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused32<true>), grid, block, lds32, st, a);
+        else hipLaunchKernelGGL((vp_k_stft_fused32<false>), grid, block, lds32, st, a);
+    } else if (a.F == 2048) {
         const size_t lds2 = lds + (64 + 512) * 16;                             // + the LDS copies of the 512-point transform's twiddle tables
         if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused2k<true>), grid, block, lds2, st, a);
         else hipLaunchKernelGGL((vp_k_stft_fused2k<false>), grid, block, lds2, st, a);

@@ -121,6 +121,8 @@ def load_library():
     L.vp_stft_pitch_shift.argtypes = [vp, fp, fp, C.c_double, C.c_void_p]
     L.vp_stft_is_fused.argtypes = [vp]
     L.vp_stft_set_runs.argtypes = [vp, C.c_int]
+    L.vp_stft_set_precision.argtypes = [vp, C.c_int]
+    L.vp_stft_get_precision.argtypes = [vp]
     L.vp_error_string.argtypes = [C.c_int]
     L.vp_error_string.restype = C.c_char_p
     L.vp_last_error.argtypes = [vp]
@@ -429,6 +431,16 @@ class StftRoundTrip:
         rc = self.L.vp_stft_set_runs(self.h, int(runs_per_stream))
         if rc:
             raise VpError(rc, self.L.vp_error_string(rc).decode())
+
+    def set_precision(self, precision):
+        """"f64" (default) or "f32": arithmetic of the round trip's transforms (vp_stft_set_precision; 1024-point frames only for f32)."""
+        rc = self.L.vp_stft_set_precision(self.h, {"f64": 0, "f32": 1}[precision])
+        if rc:
+            raise VpError(rc, self.L.vp_error_string(rc).decode())
+
+    @property
+    def precision(self):
+        return "f32" if self.L.vp_stft_get_precision(self.h) == 1 else "f64"
 
     def pitch_shift(self, d_in, d_out, semitones, stream=None):
         """Round trip with the phase-vocoder stage (per-bin phase unwrap / accumulate) shifting the pitch by `semitones`."""
