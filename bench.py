@@ -271,6 +271,21 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True):
     out["frames_2048_hop_512"] = {"frames_per_s": S * st2.n_frames / dt2, "us_per_call": dt2 * 1e6, "kernel": "vp_k_stft_fused2k<false>",
                                   "hbm_gbs_algorithmic": S * st2.n_frames * 2 * 512 * 4 / dt2 / 1e9}
     st2.close()
+    # the single-precision build of the same kernel (vp_stft_set_precision(VP_STFT_F32): transform, split and merge in f32; I/O is f32 either way)
+    st.set_precision("f32")
+    for _ in range(3):
+        st(x, y)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st(x, y)
+    torch.cuda.synchronize(dev)
+    dt3 = (time.perf_counter() - t0) / reps
+    out["single_precision"] = {"frames_per_s": frames / dt3, "us_per_call": dt3 * 1e6, "kernel": "vp_k_stft_fused32<false>", "dtype": "f32",
+                               "roofline": {"bound": "hbm", "achieved": frames / dt3 * alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": frames / dt3 * alg / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_frame": alg},
+                               "note": "opt-in; differs from the default (fp64) build by rounding only, ~1e-7 relative rms (tests/test_gpu_round4.py)"}
+    st.set_precision("f64")
     # the phase-vocoder stage between the transforms (vp_stft_pitch_shift, +7 semitones): one workgroup per stream
     if st.fused:
         for _ in range(2):

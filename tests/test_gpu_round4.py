@@ -253,12 +253,13 @@ def test_no_device_allocation_inside_any_process_call(S, voc):
 
 # ---- the fused STFT round trip (csrc/vp_stft.hip) and its phase-vocoder stage: no reference counterpart, checked against NumPy ---------
 
-def _stft_run(x, F, hop, runs=0, mag=False, semitones=None):
+def _stft_run(x, F, hop, runs=0, mag=False, semitones=None, precision="f64"):
     import torch
     from vocoderproject_amd import StftRoundTrip
     S, T = x.shape
     st = StftRoundTrip(S, T, F, hop)
     st.set_runs(runs)
+    st.set_precision(precision)
     xd = torch.from_numpy(x).cuda()
     yd = torch.full_like(xd, float("nan"))                       # every output sample must be written
     md = torch.empty((S, st.n_frames, F // 2 + 1), dtype=torch.float32, device="cuda") if mag else None
@@ -296,6 +297,42 @@ def test_fused_stft_round_trip_against_numpy(F, hop, T):
     for runs in (1, 2, 3, 7):
         y2, _, _ = _stft_run(x, F, hop, runs=runs)
         np.testing.assert_array_equal(y2, y, err_msg=f"runs={runs}")
+
+
+@pytest.mark.parametrize("hop,T", [(256, 1024 * 24), (256, 1024 * 9 + 300), (512, 1024 * 12), (128, 1024 * 6 + 128), (256, 4097), (64, 5000)])
+def test_single_precision_stft_round_trip_against_numpy(hop, T):
+    """vp_stft_set_precision(VP_STFT_F32): the same kernel with transform, split and merge in f32 (vp_k_stft_fused32).  Same checks as the
+    default build's, with the tolerance single precision earns: the whole output within 2e-6 of the NumPy restatement's scale (the
+    north_star's bound is 1e-4 RMS; measured rms ~1e-7), magnitudes to 2e-5 relative, every sample written once, and -- being the
+    same deterministic order of additions -- bit-identical across partitions into runs."""
+    import stft_reference as R
+    from vocoderproject_amd import StftRoundTrip, VpError
+    F, S = 1024, 5
+    x = _streams(S, T)[:, 0].copy()
+    x[1] *= 3.0
+    y, mag, st = _stft_run(x, F, hop, mag=True, precision="f32")
+    assert st.precision == "f32" and not np.isnan(y).any()
+    worst = 0.0
+    for s in range(S):
+        ref = R.stft_roundtrip(x[s], F, hop)
+        np.testing.assert_allclose(y[s], ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
+        worst = max(worst, float(np.sqrt(((y[s] - ref) ** 2).mean()) / max(1e-30, np.sqrt((ref ** 2).mean()))))
+    print(f"f32 STFT hop {hop} T {T}: worst relative rms error {worst:.2e}")
+    assert worst < 1e-6
+    nF = st.n_frames
+    w = R.window(F)
+    for s in (0, S - 1):
+        for f in (0, min(7, nF - 1), nF - 1):
+            ref = np.abs(np.fft.rfft(x[s, f * hop:f * hop + F].astype(np.float64) * w))
+            np.testing.assert_allclose(mag[s, f], ref, rtol=2e-5, atol=2e-5 * max(1.0, ref.max()))
+    for runs in (1, 2, 3, 7):
+        y2, _, _ = _stft_run(x, F, hop, runs=runs, precision="f32")
+        np.testing.assert_array_equal(y2, y, err_msg=f"runs={runs}")
+    y64, _, _ = _stft_run(x, F, hop)                                   # and the default is still the double-precision kernel
+    assert np.abs(y64 - y).max() < 4e-6 and not np.array_equal(y64, y)
+    with pytest.raises(VpError) as e:                                  # built for 1024-point frames
+        StftRoundTrip(2, 8192, 2048, 512).set_precision("f32")
+    assert e.value.code == -4
 
 
 def test_stft_rejects_frame_lengths_the_fused_kernel_is_not_built_for():

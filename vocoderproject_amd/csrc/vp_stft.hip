@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void vp_k_stft_fused32(VpStftArgs A)
             fft512f(z, xb, L, tw1, (const f2 *)tw2);
             wave_sync();
 #pragma unroll
-            for (int r = 0; r < 8; r++) xb[lane + 64 * r] = f2{z.re[r] * wa[r].x, -(z.im[r] * wa[r].y)};
+            for (int r = 0; r < 8; r++) lds_put(xb, lane + 64 * r, z.re[r] * wa[r].x, -(z.im[r] * wa[r].y));
         } else {
 #pragma unroll
             for (int r = 0; r < 8; r++) xb[lane + 64 * r] = f2{0.f, 0.f};
