@@ -218,13 +218,14 @@ STFT_FP64_OPS_PER_FRAME = {"v_add_f64": 378, "v_mul_f64": 163, "v_fmac_f64": 72}
 FP64_VECTOR_PEAK_TFLOPS = 78.6                                          # MI355X: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 
 
-def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True):
+def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True, precision="f64"):
     """Standalone fused STFT->iSTFT kernel (Hann, FFT, iFFT, OLA in one launch; csrc/vp_stft.hip): NO reference counterpart, reported
     apart from the metric, with its own roofline: HBM on the algorithmic 2048 B per frame (every input
     sample in once, every output sample out once) and the fp64 vector share."""
     import torch
     from vocoderproject_amd import StftRoundTrip
     st = StftRoundTrip(S, T, F, hop, device=dev.index or 0)
+    st.set_precision(precision)
     x = torch.randn((S, T), dtype=torch.float32, device=dev) * 0.1
     y = torch.empty_like(x)
     for _ in range(3):
@@ -238,6 +239,11 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True):
     frames = S * st.n_frames
     fps = frames / dt
     alg = 2 * hop * 4                                                   # bytes per frame: hop samples in, hop samples out, f32
+    if precision == "f32":                                              # (--stft-only --stft-precision f32: the rocprofv3 passes of the single-precision build)
+        return {"frames_per_s": fps, "kernel": "vp_k_stft_fused32<false>", "us_per_call": dt * 1e6, "dtype": "f32",
+                "workload": f"{S} streams x {T} samples, {F}-pt frames hop {hop}, {st.n_frames} frames per stream, one launch per call, single precision",
+                "roofline": {"bound": "hbm", "achieved": fps * alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fps * alg / 1e9 / HBM_PEAK_GBS,
+                             "alg_bytes_per_frame": alg, "alg_bytes_per_launch": alg * frames, "traffic": None}}
     n = STFT_FP64_OPS_PER_FRAME
     insts = sum(n.values())
     flops = (n["v_add_f64"] + n["v_mul_f64"] + 2 * n["v_fmac_f64"]) * 64
@@ -285,6 +291,11 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True):
                                "roofline": {"bound": "hbm", "achieved": frames / dt3 * alg / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": frames / dt3 * alg / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_frame": alg},
                                "note": "opt-in; differs from the default (fp64) build by rounding only, ~1e-7 relative rms (tests/test_gpu_round4.py)"}
+    ctr = committed_counters("vp_k_stft_fused32<false>", f"stft/S{S}/T{T}/F{F}/hop{hop}/f32")
+    if ctr:
+        out["single_precision"]["roofline"]["traffic"] = ctr.get("hbm_bytes_per_launch")
+        out["single_precision"]["roofline"]["alg_bytes_per_launch"] = alg * frames
+        out["single_precision"]["roofline"]["rocprof_avg_us"] = ctr.get("rocprof_avg_us")
     st.set_precision("f64")
     # the phase-vocoder stage between the transforms (vp_stft_pitch_shift, +7 semitones): one workgroup per stream
     if st.fused:
@@ -393,6 +404,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--stft-only", action="store_true",
                     help="time the standalone fused STFT kernel alone and print its figure (one kernel population: for the rocprofv3 passes)")
+    ap.add_argument("--stft-precision", default="f64", choices=["f64", "f32"], help="with --stft-only: which build of the kernel")
     ap.add_argument("--no-parity", action="store_true", help="skip the per-leg comparison with the CPU oracle")
     ap.add_argument("--parity-streams", type=int, default=8, help="streams of each leg's batch that are run through the CPU oracle")
     ap.add_argument("--parity-blocks", type=int, default=12, help="blocks per stream of that comparison")
@@ -442,10 +454,11 @@ def main():
     n_gpus = world
 
     if args.stft_only:
-        fig = stft_figure(dev, args.streams, reps=max(args.steps, 10), pv=False)
+        fig = stft_figure(dev, args.streams, reps=max(args.steps, 10), pv=False, precision=args.stft_precision)
         T = 1024 * 64
         line = {"stft_only": True, "value": fig["frames_per_s"], "unit": "frames/s", "kernel_us": {fig["kernel"]: fig["us_per_call"]},
-                "config": {"workload_key": f"stft/S{args.streams}/T{T}/F1024/hop256", "workload": fig["workload"]}, "stft_kernel": fig}
+                "config": {"workload_key": f"stft/S{args.streams}/T{T}/F1024/hop256" + ("/f32" if args.stft_precision == "f32" else ""),
+                           "workload": fig["workload"]}, "stft_kernel": fig}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
         return
     S, N, mode = args.streams, args.block, args.mode

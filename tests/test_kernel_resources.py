@@ -18,7 +18,7 @@ BASELINE_KERNELS = [
     "vp_k_v2_fir2<40, 8, true>", "vp_k_v2_fir2<40, 8, false>", "vp_k_v2_energy_slices", "vp_k_v2_iir_fast<3, 1>", "vp_k_v2_ola",    # configs[3]
     "vp_k_pitch_fast", "vp_k_v2_levinson2<48, 32, true>", "vp_k_v2_fir2<48, 32, true>",                      # configs[4] geometry
     "vp_k_pitch_fast_multi_c", "vp_k_emit", "vp_k_ingest_gate",
-    "vp_k_stft_fused<false, false>", "vp_k_stft_fused<true, false>",                                          # the standalone STFT figures
+    "vp_k_stft_fused<false, false>", "vp_k_stft_fused<true, false>", "vp_k_stft_fused2k<false>", "vp_k_stft_fused32<false>",      # the standalone STFT figures
 ]
 
 
@@ -75,3 +75,5 @@ def test_stft_kernel_fp64_instruction_count_matches_bench(resources):
     assert got == bench.STFT_FP64_OPS_PER_FRAME, got
     r = resources["vp_k_stft_fused<false, false>"]
     assert r["vgpr"] + r["agpr"] <= 256 and r["scratch"] == 0        # two wavefronts per SIMD (two workgroups per CU)
+    r = resources["vp_k_stft_fused32<false>"]
+    assert r["vgpr"] + r["agpr"] <= 128 and r["scratch"] == 0        # the single-precision build: four wavefronts per SIMD

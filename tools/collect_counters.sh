@@ -29,6 +29,7 @@ sel=${2:-all}
 [ $sel = all -o $sel = cfg5 ] && run cfg5_both_s512 --cfg5 --mode both --streams 512
 [ $sel = all -o $sel = cfg2x ] && run cfg2_pitch_s256_exact --iir exact
 [ $sel = all -o $sel = stft ] && run stft_s256 --stft-only
+[ $sel = all -o $sel = stft32 ] && run stft_s256_f32 --stft-only --stft-precision f32
 python3 tools/summarize_counters.py $out $tag
 # the summary as this box computed it travels back with gpurun_out/ (copy gpurun_out/ctr_<tag>/_profiles/* into profiles/)
 mkdir -p $out/_profiles

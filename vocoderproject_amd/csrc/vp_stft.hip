@@ -400,13 +400,13 @@ __global__ __launch_bounds__(64 * NWV, 4) void vp_k_stft_fused32(VpStftArgs A)
     const int r0 = max(0, rFirst - (run > 0 ? A.haloRounds : 0));
     const int r1 = min(rFirst + A.roundsPerRun, A.nRounds);
     const float *xs = A.in + (size_t)s * T;
-    for (int rd = r0; rd < r1; rd++) {
-        const int f = rd * NWV + wv;
-        const bool live = f < A.nFrames;
-        if (live) {
-            const float *x = xs + (size_t)f * hop;
-            C8f z;
-            f2 xv[8];
+    // the frame's samples are requested a round ahead (16 registers this build can afford; +3 to +8 % on one box: 570 -> 590 M frames/s at
+    // 256 streams x 65 536 samples, 675 -> 730 M at 4096 x 32 768)
+    f2 xv[8];
+    auto request = [&](int rd_) {
+        const int f_ = rd_ * NWV + wv;
+        if (rd_ < r1 && f_ < A.nFrames) {
+            const float *x = xs + (size_t)f_ * hop;
             if (A.aligned) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) xv[r] = *(const f2 *)(x + 2 * (lane + 64 * r));
@@ -414,8 +414,19 @@ __global__ __launch_bounds__(64 * NWV, 4) void vp_k_stft_fused32(VpStftArgs A)
 #pragma unroll
                 for (int r = 0; r < 8; r++) xv[r] = f2{x[2 * (lane + 64 * r)], x[2 * (lane + 64 * r) + 1]};
             }
+        }
+    };
+    request(r0);
+    for (int rd = r0; rd < r1; rd++) {
+        const int f = rd * NWV + wv;
+        const bool live = f < A.nFrames;
+        C8f z;
+        if (live) {
 #pragma unroll
             for (int r = 0; r < 8; r++) { z.re[r] = xv[r].x * wa[r].x; z.im[r] = xv[r].y * wa[r].y; }
+        }
+        request(rd + 1);
+        if (live) {
             fft512f(z, xb, L, tw1, (const f2 *)tw2);
             RPairsT<float, 4> X;
             rfft_split_n<4>(z.re, z.im, z.re + 4, z.im + 4, xb, lane, (const f2 *)ws, X);
