@@ -295,8 +295,8 @@ int vp_stft_set_runs(vp_stft *p, int runs_per_stream);
 /* Arithmetic of vp_stft_roundtrip's transforms.  VP_STFT_F64 (default): double, as everything else in this library.  VP_STFT_F32: the
  * transform, split and merge in single precision (vp_k_stft_fused32: an f32 vector instruction issues in half the cycles of an fp64 one,
  * the kernel needs half the registers and half the LDS bytes) -- input and output are float32 either way; the result differs from the
- * default's by rounding (~2e-7 of the signal's scale; the north_star's bound is 1e-4 RMS).  1024-point frames only (VP_ERR_GEOMETRY
- * otherwise); vp_stft_pitch_shift always runs in double (its phases accumulate over the whole stream). */
+ * default's by rounding (~2e-7 of the signal's scale; the north_star's bound is 1e-4 RMS).  Both frame lengths
+ * (vp_k_stft_fused32, vp_k_stft_fused2k32); vp_stft_pitch_shift always runs in double (its phases accumulate over the whole stream). */
 #define VP_STFT_F64 0
 #define VP_STFT_F32 1
 int vp_stft_set_precision(vp_stft *p, int precision);

@@ -41,3 +41,5 @@ if __name__ == "__main__":
         run(256, 65536, runs=runs, precision="f32")
     run(256, 65536, hop=512, precision="f32")
     run(256, 65536, hop=128, precision="f32")
+    run(256, 65536, F=2048, hop=512, precision="f32")
+    run(1024, 65536, F=2048, hop=512, precision="f32")

@@ -1620,7 +1620,6 @@ extern "C" int vp_stft_set_runs(vp_stft *p, int runs_per_stream)
 extern "C" int vp_stft_set_precision(vp_stft *p, int precision)
 {
     if (!p || (precision != VP_STFT_F64 && precision != VP_STFT_F32)) return VP_ERR_INVALID_ARG;
-    if (precision == VP_STFT_F32 && p->F != 1024) return VP_ERR_GEOMETRY;       // the single-precision kernel is built for 1024-point frames
     p->f32 = precision == VP_STFT_F32;
     return VP_OK;
 }
@@ -1645,8 +1644,8 @@ static int stft_fused(vp_stft *p, const float *d_in, float *d_out, float *d_mag,
     // the phase-vocoder stage carries a recurrence over the frames of a stream: one run
     int runs = 1;
     if (!pv) {
-        // (four workgroups per CU in the single-precision build: half the registers)
-        runs = p->runsPerStream > 0 ? p->runsPerStream : ((a.f32 ? 4 : 2) * 256 + p->S - 1) / p->S;
+        // (four workgroups per CU in the single-precision build -- half the registers --, three at 2048 points)
+        runs = p->runsPerStream > 0 ? p->runsPerStream : ((a.f32 ? (p->F == 2048 ? 3 : 4) : 2) * 256 + p->S - 1) / p->S;
         runs = std::max(1, std::min(runs, a.nRounds / (4 * a.haloRounds)));
     }
     a.roundsPerRun = (a.nRounds + runs - 1) / runs;

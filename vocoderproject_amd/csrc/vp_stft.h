@@ -22,7 +22,7 @@ struct VpStftArgs {
     int F, hop, O;                      // frame, hop, overlap factor F / hop
     int aligned;                        // rows and hops 8-byte aligned: float2 loads
     int pv;                             // 1: phase-vocoder stage between the transforms (one workgroup per stream), 0: identity
-    int f32;                            // 1: transform, split and merge in single precision (vp_k_stft_fused32; F = 1024, no phase-vocoder stage)
+    int f32;                            // 1: transform, split and merge in single precision (vp_k_stft_fused32 / vp_k_stft_fused2k32; no phase-vocoder stage)
 };
 
 size_t vp_stft_lds_bytes(int F, int hop, int f32 = 0);

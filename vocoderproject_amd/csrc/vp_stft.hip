@@ -455,6 +455,110 @@ __global__ __launch_bounds__(64 * NWV, 4) void vp_k_stft_fused32(VpStftArgs A)
     }
 }
 
+// single precision, 2048-point frames: vp_k_stft_fused2k's radix-2 step over two 512-point transforms, in f32.  The wavefront's output slot
+// (8 KB) starts with its exchange buffer (4 KB); window (f32, 8 KB) and the 512-point twiddles (4.5 KB) are LDS copies: 51 KB per
+// workgroup, three workgroups per CU.
+template <bool MAG>
+__global__ __launch_bounds__(64 * NWV, 3) void vp_k_stft_fused2k32(VpStftArgs A)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = blockIdx.y, run = blockIdx.x;
+    constexpr int N = 1024;
+    const int F = A.F, hop = A.hop, T = A.T;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) f4 lds_f4;
+    lds_f32 *slots = (lds_f32 *)smem;                                          // slot w: 2048 floats at w * 2048
+    lds_f32 *carry = slots + NWV * 2048;
+    lds_f2 *xb = (lds_f2 *)(slots + wv * 2048);
+    lds_f4 *winL = (lds_f4 *)((lds_f32 *)smem + stft_lds_base(F, hop, 0) / 4);              // [512] the window, four consecutive samples per entry
+    lds_f2 *twL = (lds_f2 *)(winL + 512);                                                    // [8][8] W_64 rows | [64][8] W_512
+    Fft32Addr L;
+    fft32_addr_init(L, lane);
+    for (int i = tid; i < 64; i += 64 * NWV) { const d2 t = ((const d2 *)A.tw1)[(i >> 3) * 64 + (i & 7)]; twL[i] = f2{(float)t.x, (float)t.y}; }
+    for (int i = tid; i < 512; i += 64 * NWV) { const d2 t = ((const d2 *)A.tw2)[i]; twL[64 + i] = f2{(float)t.x, (float)t.y}; }
+    const lds_f2 *tw1p = twL + (lane >> 3) * 8, *tw2p = twL + 64 + lane * 8;
+    for (int i = tid; i < 512; i += 64 * NWV) {
+        const d2 w0 = ((const d2 *)A.win)[2 * i], w1 = ((const d2 *)A.win)[2 * i + 1];
+        winL[i] = f4{(float)w0.x, (float)w0.y, (float)w1.x, (float)w1.y};
+    }
+    f2 wtop[8], ws[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const d2 t = ((const d2 *)A.twTop)[lane * 8 + q], u = ((const d2 *)A.tws)[lane * 8 + q];
+        wtop[q] = f2{(float)t.x, (float)t.y}; ws[q] = f2{(float)u.x, (float)u.y};
+    }
+    const float c = (float)A.c;
+    for (int i = tid; i < F - hop; i += 64 * NWV) carry[i] = 0.f;
+    __syncthreads();
+
+    const int rFirst = run * A.roundsPerRun;
+    const int r0 = max(0, rFirst - (run > 0 ? A.haloRounds : 0));
+    const int r1 = min(rFirst + A.roundsPerRun, A.nRounds);
+    const float *xs = A.in + (size_t)s * T;
+    for (int rd = r0; rd < r1; rd++) {
+        const int f = rd * NWV + wv;
+        const bool live = f < A.nFrames;
+        lds_f4 *slot = (lds_f4 *)(slots + wv * 2048);
+        if (live) {
+            const float *x = xs + (size_t)f * hop;
+            C8f e, o;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int m = lane + 64 * r;
+                f4 v;
+                if (A.aligned) v = *(const f4 *)(x + 4 * m);
+                else v = f4{x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]};
+                const f4 w = winL[m];
+                e.re[r] = v.x * w.x; e.im[r] = v.y * w.y;
+                o.re[r] = v.z * w.z; o.im[r] = v.w * w.w;
+            }
+            fft512f(e, xb, L, tw1p, tw2p);
+            fft512f(o, xb, L, tw1p, tw2p);
+            float hr[8], hi[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float tr = vp_fma(o.re[q], wtop[q].x, -(o.im[q] * wtop[q].y)), ti = vp_fma(o.re[q], wtop[q].y, o.im[q] * wtop[q].x);
+                hr[q] = e.re[q] - tr; hi[q] = e.im[q] - ti;
+                e.re[q] += tr; e.im[q] += ti;
+            }
+            RPairsT<float, 8> X;
+            rfft_split_n<8>(e.re, e.im, hr, hi, xb, lane, (const f2 *)ws, X);
+            if (MAG) {
+                float *mg = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int k = 64 * q + lane;
+                    mg[k] = sqrtf(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]);
+                    mg[N - k] = sqrtf(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]);
+                }
+                if (lane == 0) mg[N / 2] = sqrtf(X.hr * X.hr + X.hi * X.hi);
+            }
+            rfft_merge_conj_n<8>(e.re, e.im, hr, hi, xb, lane, (const f2 *)ws, X, c);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const float dr = e.re[q] - hr[q], di = e.im[q] - hi[q];
+                e.re[q] += hr[q]; e.im[q] += hi[q];
+                o.re[q] = vp_fma(dr, wtop[q].x, -(di * wtop[q].y)); o.im[q] = vp_fma(dr, wtop[q].y, di * wtop[q].x);
+            }
+            fft512f(e, xb, L, tw1p, tw2p);
+            fft512f(o, xb, L, tw1p, tw2p);
+            wave_sync();                                                       // (the slot starts with the exchange buffer)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const f4 w = winL[lane + 64 * r];
+                slot[lane + 64 * r] = f4{e.re[r] * w.x, -(e.im[r] * w.y), o.re[r] * w.z, -(o.im[r] * w.w)};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) slot[lane + 64 * r] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        stft_overlap_add(A, slots, carry, s, rd, rd >= rFirst, tid);
+        __syncthreads();
+    }
+}
+
 hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStream_t st)
 {
     static bool attr = false;
@@ -464,7 +568,12 @@ hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStrea
     }
     const size_t lds = vp_stft_lds_bytes(a.F, a.hop, a.f32);
     const dim3 grid(nRuns, nStreams), block(64 * NWV);
-    if (a.f32) {
+    if (a.f32 && a.F == 2048) {
+        // slots + carry as in the double-precision build, then the f32 copies of the window and of the 512-point twiddle tables
+        const size_t lds2k = vp_stft_lds_bytes(a.F, a.hop, 0) + 2048 * 4 + (64 + 512) * 8;
+        if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused2k32<true>), grid, block, lds2k, st, a);
+        else hipLaunchKernelGGL((vp_k_stft_fused2k32<false>), grid, block, lds2k, st, a);
+    } else if (a.f32) {
         const size_t lds32 = lds + 64 * 8;                                      // + the second step's twiddle rows
         if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused32<true>), grid, block, lds32, st, a);
         else hipLaunchKernelGGL((vp_k_stft_fused32<false>), grid, block, lds32, st, a);

@@ -433,7 +433,7 @@ class StftRoundTrip:
             raise VpError(rc, self.L.vp_error_string(rc).decode())
 
     def set_precision(self, precision):
-        """"f64" (default) or "f32": arithmetic of the round trip's transforms (vp_stft_set_precision; 1024-point frames only for f32)."""
+        """"f64" (default) or "f32": arithmetic of the round trip's transforms (vp_stft_set_precision)."""
         rc = self.L.vp_stft_set_precision(self.h, {"f64": 0, "f32": 1}[precision])
         if rc:
             raise VpError(rc, self.L.vp_error_string(rc).decode())
