@@ -44,8 +44,12 @@ def lite_case(seed):
     pick = [0, 12, 130, 259]
     small = run(np.ascontiguousarray(x[pick]))
     dlt = np.abs(big[pick].astype(np.float64) - small)
-    assert dlt.max() <= 4e-7 * max(1.0, float(np.abs(small).max())) and (big[pick] != small).mean() < 0.02, \
-        f"lite vs regular, seed {seed}: fs={fs} N={N} {params}: max diff {dlt.max()}"
+    # (round 4: with the vocoder on, the large batch runs the lane-per-window pipeline, whose tolerance mode keeps two intermediates in
+    # f32 -- last-bit differences are then the rule, bounded in size; the pitch corrector alone still only flips the odd last bit)
+    scale = max(1.0, float(np.abs(small).max()))
+    few = (big[pick] != small).mean() < 0.02 if not params["vocBool"] else float(np.sqrt((dlt ** 2).mean())) < 6e-8 * scale
+    assert dlt.max() <= 4e-7 * scale and few, \
+        f"lite vs regular, seed {seed}: fs={fs} N={N} {params}: max diff {dlt.max()}, differing {(big[pick] != small).mean():.3f}, rms {np.sqrt((dlt ** 2).mean()):.2e}"
     if params["pitchBool"] or params["vocBool"]:
         assert np.abs(big).max() > 0.01, "vacuous comparison"
 

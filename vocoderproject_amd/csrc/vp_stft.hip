@@ -139,14 +139,12 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
     const int r0 = max(0, rFirst - (run > 0 ? A.haloRounds : 0));
     const int r1 = min(rFirst + A.roundsPerRun, A.nRounds);
     const float *xs = A.in + (size_t)s * T;
-    for (int rd = r0; rd < r1; rd++) {
-        const int f = rd * NWV + wv;
-        const bool live = f < A.nFrames;                                       // (wavefront-uniform)
-        C8 z;
-        RPairs X;                                                              // X[k], X[N - k] of the lane's pairs (vp_fft.inc)
-        if (live) {
-            const float *x = xs + (size_t)f * hop;
-            f2 xv[8];
+    // the frame's samples are requested a round ahead (see vp_k_stft_fused32)
+    f2 xv[8];
+    auto request = [&](int rd_) {
+        const int f_ = rd_ * NWV + wv;
+        if (rd_ < r1 && f_ < A.nFrames) {
+            const float *x = xs + (size_t)f_ * hop;
             if (A.aligned) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) xv[r] = *(const f2 *)(x + 2 * (lane + 64 * r));
@@ -154,8 +152,20 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
 #pragma unroll
                 for (int r = 0; r < 8; r++) xv[r] = f2{x[2 * (lane + 64 * r)], x[2 * (lane + 64 * r) + 1]};
             }
+        }
+    };
+    request(r0);
+    for (int rd = r0; rd < r1; rd++) {
+        const int f = rd * NWV + wv;
+        const bool live = f < A.nFrames;                                       // (wavefront-uniform)
+        C8 z;
+        RPairs X;                                                              // X[k], X[N - k] of the lane's pairs (vp_fft.inc)
+        if (live) {
 #pragma unroll
             for (int r = 0; r < 8; r++) { z.re[r] = (double)xv[r].x * wa[r].x; z.im[r] = (double)xv[r].y * wa[r].y; }
+        }
+        request(rd + 1);
+        if (live) {
             fft512(z, xb, L);
             rfft_split(z, xb, lane, (const d2 *)ws, X);
             if (MAG) {                                                         // |X[k]|, k <= N, natural order
