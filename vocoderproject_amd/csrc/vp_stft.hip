@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void vp_k_stft_fused32(VpStftArgs A)
 }
 
 // single precision, 2048-point frames: vp_k_stft_fused2k's radix-2 step over two 512-point transforms, in f32.  The wavefront's output slot
-// (8 KB) starts with its exchange buffer (4 KB); window (f32, 8 KB) and the 512-point twiddles (4.5 KB) are LDS copies: 51 KB per
+// (8 KB) starts with its exchange buffer (4 KB); the window (f32, 8 KB) and the second step's twiddle rows are LDS copies: 47 KB per
 // workgroup, three workgroups per CU.
 template <bool MAG>
 __global__ __launch_bounds__(64 * NWV, 3) void vp_k_stft_fused2k32(VpStftArgs A)
@@ -482,22 +482,27 @@ __global__ __launch_bounds__(64 * NWV, 3) void vp_k_stft_fused2k32(VpStftArgs A)
     lds_f32 *carry = slots + NWV * 2048;
     lds_f2 *xb = (lds_f2 *)(slots + wv * 2048);
     lds_f4 *winL = (lds_f4 *)((lds_f32 *)smem + stft_lds_base(F, hop, 0) / 4);              // [512] the window, four consecutive samples per entry
-    lds_f2 *twL = (lds_f2 *)(winL + 512);                                                    // [8][8] W_64 rows | [64][8] W_512
+    lds_f2 *twL = (lds_f2 *)(winL + 512);                                                    // [8][8] W_64 rows (| [64][8] W_512 in the magnitude-dump build)
     Fft32Addr L;
     fft32_addr_init(L, lane);
     for (int i = tid; i < 64; i += 64 * NWV) { const d2 t = ((const d2 *)A.tw1)[(i >> 3) * 64 + (i & 7)]; twL[i] = f2{(float)t.x, (float)t.y}; }
-    for (int i = tid; i < 512; i += 64 * NWV) { const d2 t = ((const d2 *)A.tw2)[i]; twL[64 + i] = f2{(float)t.x, (float)t.y}; }
-    const lds_f2 *tw1p = twL + (lane >> 3) * 8, *tw2p = twL + 64 + lane * 8;
+    const lds_f2 *tw1p = twL + (lane >> 3) * 8;
     for (int i = tid; i < 512; i += 64 * NWV) {
         const d2 w0 = ((const d2 *)A.win)[2 * i], w1 = ((const d2 *)A.win)[2 * i + 1];
         winL[i] = f4{(float)w0.x, (float)w0.y, (float)w1.x, (float)w1.y};
     }
-    f2 wtop[8], ws[8];
+    // the third step's twiddles are the lane's own: registers (the magnitude-dump build, which is not the timed one, has none to spare
+    // and reads them from an LDS copy)
+    f2 wtop[8], ws[8], tw2r[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const d2 t = ((const d2 *)A.twTop)[lane * 8 + q], u = ((const d2 *)A.tws)[lane * 8 + q];
+        const d2 t = ((const d2 *)A.twTop)[lane * 8 + q], u = ((const d2 *)A.tws)[lane * 8 + q], v = ((const d2 *)A.tw2)[lane * 8 + q];
         wtop[q] = f2{(float)t.x, (float)t.y}; ws[q] = f2{(float)u.x, (float)u.y};
+        if (MAG) twL[64 + lane * 8 + q] = f2{(float)v.x, (float)v.y}; else tw2r[q] = f2{(float)v.x, (float)v.y};
     }
+    auto fft = [&](C8f &z_) {
+        if (MAG) fft512f(z_, xb, L, tw1p, (const lds_f2 *)(twL + 64 + lane * 8)); else fft512f(z_, xb, L, tw1p, (const f2 *)tw2r);
+    };
     const float c = (float)A.c;
     for (int i = tid; i < F - hop; i += 64 * NWV) carry[i] = 0.f;
     __syncthreads();
@@ -523,8 +528,8 @@ __global__ __launch_bounds__(64 * NWV, 3) void vp_k_stft_fused2k32(VpStftArgs A)
                 e.re[r] = v.x * w.x; e.im[r] = v.y * w.y;
                 o.re[r] = v.z * w.z; o.im[r] = v.w * w.w;
             }
-            fft512f(e, xb, L, tw1p, tw2p);
-            fft512f(o, xb, L, tw1p, tw2p);
+            fft(e);
+            fft(o);
             float hr[8], hi[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -551,8 +556,8 @@ __global__ __launch_bounds__(64 * NWV, 3) void vp_k_stft_fused2k32(VpStftArgs A)
                 e.re[q] += hr[q]; e.im[q] += hi[q];
                 o.re[q] = vp_fma(dr, wtop[q].x, -(di * wtop[q].y)); o.im[q] = vp_fma(dr, wtop[q].y, di * wtop[q].x);
             }
-            fft512f(e, xb, L, tw1p, tw2p);
-            fft512f(o, xb, L, tw1p, tw2p);
+            fft(e);
+            fft(o);
             wave_sync();                                                       // (the slot starts with the exchange buffer)
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -579,9 +584,9 @@ hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStrea
     const size_t lds = vp_stft_lds_bytes(a.F, a.hop, a.f32);
     const dim3 grid(nRuns, nStreams), block(64 * NWV);
     if (a.f32 && a.F == 2048) {
-        // slots + carry as in the double-precision build, then the f32 copies of the window and of the 512-point twiddle tables
-        const size_t lds2k = vp_stft_lds_bytes(a.F, a.hop, 0) + 2048 * 4 + (64 + 512) * 8;
-        if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused2k32<true>), grid, block, lds2k, st, a);
+        // slots + carry as in the double-precision build, then the f32 copies of the window and of the second step's twiddle rows
+        const size_t lds2k = vp_stft_lds_bytes(a.F, a.hop, 0) + 2048 * 4 + 64 * 8;
+        if (a.mag) hipLaunchKernelGGL((vp_k_stft_fused2k32<true>), grid, block, lds2k + 512 * 8, st, a);
         else hipLaunchKernelGGL((vp_k_stft_fused2k32<false>), grid, block, lds2k, st, a);
     } else if (a.f32) {
         const size_t lds32 = lds + 64 * 8;                                      // + the second step's twiddle rows
