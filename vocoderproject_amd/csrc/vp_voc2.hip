@@ -139,24 +139,32 @@ __global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, 
 // FS (VP_IIR_FAST, round 3): the lane's ring holds the WINDOWED samples x[n+m] w[n+m] (one multiply per new sample) and a term is
 // ONE fused multiply-add tmp[n] * (x w)[n+m] instead of two multiplies and an add -- 2.2x fewer vector instructions per trip.  The
 // reference's association ((x[n] w[n]) x[n+m]) w[n+m] and its two roundings per term are given up: tolerance-mode arithmetic.
+// V2_AC_WAVES wavefronts (consecutive 64-window groups, the same lags) per workgroup (round 4).  A workgroup's wavefronts are dealt to
+// the CU's four SIMDs in turn; single-wavefront workgroups are not: the 896 of them this kernel is at 1024 streams left some of the 1024
+// SIMDs with two of these issue-bound wavefronts and others with none, and the kernel lasted as long as the doubly loaded SIMDs --
+// 37.9 us against 26.1 us for the same wavefronts four to a workgroup (with its loads replaced by constants the old form still took
+// 30 us: that is how it was found).  The pipeline's other lane-per-window kernels were measured the same way and stay one wavefront
+// per workgroup: they are latency-bound (two of their wavefronts on a SIMD overlap) or have several wavefronts per SIMD anyway --
+// vp_k_v2_iir_fast 31.1 -> 30.8 us, vp_k_v2_fir2 16.8 -> 17.0, vp_k_v2_levinson2 12.3 -> 12.4, vp_k_v2_iir_exact<40> 157 -> 162.
+#define V2_AC_WAVES 4
 template <int L, bool FS = false>
-__global__ __launch_bounds__(64) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev d, VpV2 v)
+__global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
     static_assert(L == 4 || L == 8, "lag groups of 4 or 8");
     extern __shared__ double smem[];
-    const int lane = threadIdx.x, w = blockIdx.x * WAVE + lane;
+    const int lane = threadIdx.x & 63, w = (blockIdx.x * V2_AC_WAVES + (threadIdx.x >> 6)) * WAVE + lane;
     const int gV = (v.oVmax + L) / L;                                     // lag groups of the voice: ceil((oVmax + 1) / L)
     const bool isS = (int)blockIdx.y >= gV;
     const int m0 = (isS ? (int)blockIdx.y - gV : (int)blockIdx.y) * L;
     const V2Win q = v2_window(c, d, v, w);
-    if (!__any(q.live)) return;
     const int W = g.W;
-    const V2X x = v2_x(v, isS ? 1 : 0, q.b * c.nWin + q.j);
     // the window function in LDS (uniform reads = broadcasts).  Scalar loads would do, but they return out of order, so each
     // one has to be waited for on its own (lgkmcnt(0)) and the loop stalls three times per trip; LDS reads pipeline.
     lds_f64 *wl = (lds_f64 *)smem;
-    for (int i = lane; i < W + 16; i += WAVE) wl[i] = (i < W) ? d.vocWin[i] : 0.0;
+    for (int i = threadIdx.x; i < W + 16; i += 64 * V2_AC_WAVES) wl[i] = (i < W) ? d.vocWin[i] : 0.0;
     __syncthreads();
+    if (!__any(q.live)) return;
+    const V2X x = v2_x(v, isS ? 1 : 0, q.b * c.nWin + q.j);
     double sum[L];
 #pragma unroll
     for (int j = 0; j < L; j++) sum[j] = 0.0;
@@ -836,16 +844,20 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
     if (NW <= 0) return;
     // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
     static const int forceL = getenv("VP_V2_AC_L") ? atoi(getenv("VP_V2_AC_L")) : 0;     // (diagnostic)
-    // (the fused-multiply-add form is lighter on the vector ALUs and bound by its loads, which eight lags per wavefront halve: it takes
-    // the switch a little earlier -- 1024 streams at the default geometry are 896 such wavefronts: 158 -> 155 us)
-    if (forceL ? forceL == 8 : nGroups * ((v.oVmax + 8) / 8 + (v.oSmax + 8) / 8) >= ((c.iirFast && v2_ac_fs()) ? 832 : 1024)) {
+    // (round 4, with the wavefronts placed evenly: four lags per wavefront while those workgroups still get a CU each -- the
+    // wavefronts are then alone on their SIMDs and half as long --, eight beyond that)
+    static const int nCus = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    const int wgs4 = ((nGroups + V2_AC_WAVES - 1) / V2_AC_WAVES) * ((v.oVmax + 4) / 4 + (v.oSmax + 4) / 4);
+    if (forceL ? forceL == 8 : wgs4 > nCus) {
         const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
-        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<8, true>), dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
-        else V2_LAUNCH(vp_k_v2_autocorr<8>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
+        const dim3 ga((nGroups + V2_AC_WAVES - 1) / V2_AC_WAVES, gy), ba(64 * V2_AC_WAVES);
+        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<8, true>), ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
+        else V2_LAUNCH(vp_k_v2_autocorr<8>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
     } else {
         const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
-        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<4, true>), dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
-        else V2_LAUNCH(vp_k_v2_autocorr<4>, dim3(nGroups, gy), dim3(64), (size_t)(g.W + 16) * 8, g, c, d, v);
+        const dim3 ga((nGroups + V2_AC_WAVES - 1) / V2_AC_WAVES, gy), ba(64 * V2_AC_WAVES);
+        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<4, true>), ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
+        else V2_LAUNCH(vp_k_v2_autocorr<4>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
     }
     v2_launch_lpc_fir(v.oVmax, v.oSmax, nGroups, g.W, st, g, c, d, v);
     if (c.iirFast) {
