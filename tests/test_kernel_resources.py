@@ -15,7 +15,7 @@ BASELINE_KERNELS = [
     "vp_k_pitch_fast_c", "vp_k_pitch_c",                      # configs[1]: 256 streams, pitch corrector (FAST / bit-exact)
     "vp_k_vocoder",                                           # configs[2]: 256 streams, vocoder, LPC order 24
     "vp_k_pitch_lite_fast_c", "vp_k_v2_ingest_stage", "vp_k_v2_autocorr<4, true>", "vp_k_v2_autocorr<8, true>", "vp_k_v2_autocorr<4, false>", "vp_k_v2_autocorr<8, false>", "vp_k_v2_levinson2<40, 8, true>", "vp_k_v2_levinson2<40, 8, false>",
-    "vp_k_v2_fir2<40, 8, true>", "vp_k_v2_fir2<40, 8, false>", "vp_k_v2_energy_slices", "vp_k_v2_iir_fast<3, 1>", "vp_k_v2_ola",    # configs[3]
+    "vp_k_v2_fir2<40, 8, true>", "vp_k_v2_fir2<40, 8, false>", "vp_k_v2_iir_fast<3, 1>", "vp_k_v2_ola",    # configs[3]
     "vp_k_pitch_fast", "vp_k_v2_levinson2<48, 32, true>", "vp_k_v2_fir2<48, 32, true>",                      # configs[4] geometry
     "vp_k_pitch_fast_multi_c", "vp_k_emit", "vp_k_ingest_gate",
     "vp_k_stft_fused<false, false>", "vp_k_stft_fused<true, false>", "vp_k_stft_fused2k<false>", "vp_k_stft_fused32<false>", "vp_k_stft_fused2k32<false>",      # the standalone STFT figures

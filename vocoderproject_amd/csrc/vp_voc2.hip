@@ -429,22 +429,6 @@ __global__ __launch_bounds__(64) void vp_k_v2_fir2(VpGeom g, VpCall c, VpDev d, 
     else v2_fir_body<PS, FS>(g, c, d, v, 1);
 }
 
-// VP_IIR_FAST: window energies as the in-order sum of the slices' sums.  (A kernel of its own, 5 us: summed inside the
-// recursion kernel's gain prologue instead -- 160 dependent-latency loads per lane -- it cost that kernel 12 us.)
-__global__ __launch_bounds__(64) void vp_k_v2_energy_slices(VpGeom g, VpCall c, VpDev d, VpV2 v)
-{
-    const int w = blockIdx.x * WAVE + threadIdx.x;
-    const V2Win q = v2_window(c, d, v, w);
-    if (!q.live) return;
-    const int nS = (g.W + V2_FIR_SLICE - 1) / V2_FIR_SLICE;
-    for (int which = 0; which < 2; which++) {
-        const double *pp = v.EEp + ((size_t)w * 2 + which) * v.nSlices;
-        double E = 0.0;
-        for (int k = 0; k < nS; k++) E += pp[k];
-        v.EE[(size_t)w * 2 + which] = E;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // energy: E = sum e[i]^2 left to right (VocoderProcess.cpp:250), lane = window, blockIdx.y = 0: eVoice, 1: eSynth.
 // Eight entries per trip, the next trip's requested before this trip's squares and ordered adds.  -> EE[w][2]
@@ -506,6 +490,37 @@ __device__ __forceinline__ double v2_gain(const VpGeom &g, const VpDev &d, const
     return sqrt(sv / ss);
 }
 
+// The same gain by the sixteen lanes of a ROW that serves one window (vp_k_v2_iir_fast, round 4): lane t < 10 of the row takes history
+// entry t of both energies -- a window of this launch as the in-order sum of its slices' partial sums (what vp_k_v2_energy_slices, a
+// kernel of its own until then, computed: 5-8 us of launch and one round trip for a few kilobytes), an older one from EeArr -- and
+// the two sums over the ten entries run through the row broadcast in the order t = 0 .. 9: the same additions in the same order as
+// v2_gain, so the result is bit-identical.  Lane 0's entries are the window's own energies: it leaves them in EE for the overlap-add
+// kernel's history write-back.  All 64 lanes must call (DPP row operations).
+__device__ __forceinline__ double v2_gain_row(const VpGeom &g, const VpDev &d, const VpV2 &v, int s, int wBase, int j, int m, bool live)
+{
+    double hv = 0.0, hs = 0.0;
+    if (m < 10) {
+        const int rr = v.rank[wBase + j] - 1 - m;
+        if (rr >= 0) {
+            const int nS = (g.W + V2_FIR_SLICE - 1) / V2_FIR_SLICE;
+            const double *pv = v.EEp + ((size_t)(wBase + v.liveList[wBase + rr]) * 2) * v.nSlices, *ps = pv + v.nSlices;
+            for (int k = 0; k < nS; k++) { hv += pv[k]; hs += ps[k]; }
+        } else {
+            hv = d.EeArr[(size_t)s * 20 - rr - 1];
+            hs = d.EeArr[(size_t)s * 20 + 10 - rr - 1];
+        }
+        if (m == 0 && live) { v.EE[(size_t)(wBase + j) * 2 + 0] = hv; v.EE[(size_t)(wBase + j) * 2 + 1] = hs; }
+    }
+    const double one = vp_one();
+    double sv = 0.0, ss = 0.0, hs0 = 0.0;
+    asm volatile("s_nop 1" : "+v"(hv), "+v"(hs), "+v"(sv), "+v"(ss), "+v"(hs0));      // VALU write -> DPP read
+    VP_FMAC_BCAST(hs0, hs, one, 0);
+#define V2_GR(U) VP_FMAC_BCAST(sv, hv, one, U); VP_FMAC_BCAST(ss, hs, one, U);
+    V2_GR(0) V2_GR(1) V2_GR(2) V2_GR(3) V2_GR(4) V2_GR(5) V2_GR(6) V2_GR(7) V2_GR(8) V2_GR(9)
+#undef V2_GR
+    return (hs0 > g.eeFloor) ? sqrt(sv / ss) : 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // iir, EXACT: out[i] = g e[i] - sum_{k=1..min(order,i)} out[i-k] a[k] in the reference's order (VocoderProcess.cpp:277-286),
 // lane = window: the register-resident chain of vp_k_vocoder (iir_exact_lane), now with 64 different windows in the lanes.
@@ -560,7 +575,7 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
         any = any || q.live;
         es[k] = v2_ef(v, wc);
         out[k] = (float *)v.out + (size_t)wc * W;
-        gg[k] = v2_gain(g, d, v, q.s, q.b * c.nWin, q.j);
+        gg[k] = v2_gain_row(g, d, v, q.s, q.b * c.nWin, q.j, m, q.live);
         const V2Col ag = v2_col(v.aV, V2_RV_STRIDE, wc);
 #pragma unroll
         for (int j = 0; j < T; j++) { const int kk = m * T + 1 + j; na[k][j] = (kk <= q.oV) ? -ag[kk] : 0.0; st[k][j] = 0.0; }
@@ -861,7 +876,7 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
     }
     v2_launch_lpc_fir(v.oVmax, v.oSmax, nGroups, g.W, st, g, c, d, v);
     if (c.iirFast) {
-        V2_LAUNCH(vp_k_v2_energy_slices, dim3(nGroups), dim3(64), 0, g, c, d, v);
+        // (the window energies and gains are formed inside the recursion kernel: v2_gain_row)
         // (two windows per row interleaved, NI = 2, was tried for few, long windows: 82 -> 133 us at the configs[4] geometry)
         const int Tt = (v.oVmax + 15) / 16;
         const dim3 gi((NW + 3) / 4);
