@@ -92,13 +92,31 @@ __device__ __forceinline__ V2EF v2_ef(const VpV2 &v, int w)
     return r;
 }
 
-// stage: every window of the block, sample by sample (ring wrap resolved here), voice and side-chain channel 0
-__device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v)
+// stage: every window of the block, sample by sample (ring wrap resolved here), voice and side-chain channel 0.
+// spanLds > 0 (round 4; the launch grants 2 x spanLds floats of dynamic LDS): the samples the block's windows cover -- one contiguous
+// stretch of the ring, (nWin - 1) hop + W samples -- are first read into LDS with coalesced loads, and the tiles are built from there.
+// Read straight from the ring, a wavefront's 64 lanes (eight windows a hop apart x eight positions) touched 64 cache lines per load
+// instruction, eight instructions per tile entry: the kernel was bound by that gather (21.5 us for 86 MB at 1024 streams).
+__device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int spanLds)
 {
+    extern __shared__ float v2_stage_lds[];
     const int s = vp_stream(d), b = blockIdx.x;
     const float *vr = d.voiceRing + (size_t)s * g.inSize;
     const float *sr0 = d.synthRing + (size_t)s * 2 * g.inSize;
     const int W4 = (g.W + 3) >> 2;
+    const int span = (c.nWin - 1) * g.h + g.W;
+    const bool viaLds = spanLds >= span && c.nWin > 0;
+    if (viaLds) {
+        int p = ring_pos(c.currCounter, c.vStart + (int)threadIdx.x, g.inSize);
+        const int step = blockDim.x % g.inSize;
+        for (int t = threadIdx.x; t < span; t += blockDim.x) {
+            v2_stage_lds[t] = vr[p];
+            v2_stage_lds[spanLds + t] = sr0[p];
+            p += step;
+            p -= (p >= g.inSize) ? g.inSize : 0;
+        }
+        __syncthreads();
+    }
     if ((int)threadIdx.x < c.nWin) {
         const VpStreamParams sp = d.pitch[s].sp;
         const int live = d.gate[s * 2 + 0] && d.gate[s * 2 + 1];
@@ -109,14 +127,24 @@ __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c,
     for (int t = threadIdx.x; t < c.nWin * W4; t += blockDim.x) {
         const int i4 = t / c.nWin, j = t - i4 * c.nWin;                       // window fastest: the stream's windows are adjacent lanes of the tile
         const int w = b * c.nWin + j;
-        int p = ring_pos(c.currCounter, c.vStart + j * g.h + 4 * i4, g.inSize);
         float a4[4], b4[4];
+        if (viaLds) {
+            const int q0 = j * g.h + 4 * i4;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = 4 * i4 + u < g.W;
+                a4[u] = in ? v2_stage_lds[q0 + u] : 0.0f;
+                b4[u] = in ? v2_stage_lds[spanLds + q0 + u] : 0.0f;
+            }
+        } else {
+        int p = ring_pos(c.currCounter, c.vStart + j * g.h + 4 * i4, g.inSize);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const bool in = 4 * i4 + u < g.W;
             a4[u] = in ? vr[p] : 0.0f;
             b4[u] = in ? sr0[p] : 0.0f;
             p = (p + 1 == g.inSize) ? 0 : p + 1;
+        }
         }
         float *xv = v.xT + ((((size_t)(w >> 6)) * v.W4p + i4) * 64 + (w & 63)) * 4;
         float *xs = xv + (size_t)v.nGroupsMax * v.W4p * 256;
@@ -125,10 +153,10 @@ __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c,
     }
 }
 
-__global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, VpDev d, VpV2 v, const float *__restrict__ in)
+__global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, VpDev d, VpV2 v, const float *__restrict__ in, int spanLds)
 {
     if (c.fuseIngest) ingest_gate_block(g, c, d, in);                      // (ends with a barrier: the ring is visible)
-    v2_stage_block(g, c, d, v);
+    v2_stage_block(g, c, d, v, spanLds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,6 +674,9 @@ __global__ __launch_bounds__(64) void vp_k_v2_iir_fast(VpGeom g, VpCall c, VpDev
 // ola: every output sample adds its covering windows in window order -- the order of the reference's addOutSample calls
 // (VocoderProcess.cpp:291-295, MyBuffer.cpp:181-191) -- each term gainVoc * out[i] * stWindow[i]; optionally the emit
 // epilogue.  Workgroup = stream.
+// (round 4, measured and dropped: the emitted block's samples handed to the emit epilogue through LDS instead of through the accumulator
+// ring -- 16 bytes per output sample less -- 12.0 -> 13.9 us at 1024 streams, 18.1 -> 21.9 us at the configs[4] geometry: the kernel
+// is not bound by those bytes)
 __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, VpV2 v, float *__restrict__ out)
 {
     const int s = vp_stream(d), b = blockIdx.x, tid = threadIdx.x;
@@ -659,11 +690,16 @@ __global__ __launch_bounds__(256) void vp_k_v2_ola(VpGeom g, VpCall c, VpDev d, 
         const size_t o0 = (size_t)b * c.nWin * g.W;
         double *acc = d.outAcc + (size_t)s * g.outSize;
         const int W = g.W, span = (c.nWin - 1) * g.h + W;
+        // (per output sample: no division by a run-time value -- the ring position is a once-reduced base plus a compare-and-subtract
+        // (span <= outSize), the covering windows come from shifts when the hop is a power of two; ~75 vector instructions less per sample)
+        const int base = __builtin_amdgcn_readfirstlane((c.outCounter + c.vStart) % g.outSize);
+        const int hsh = (g.h & (g.h - 1)) == 0 ? __builtin_ctz(g.h) : -1;
         auto run = [&](auto *o) {                                             // (o: the block's windows, f32 in VP_IIR_FAST mode, else f64)
         for (int t = tid; t < span; t += blockDim.x) {
-            int pos = (c.outCounter + c.vStart + t) % g.outSize;
+            int pos = base + t;
+            pos -= (pos >= g.outSize) ? g.outSize : 0;
             double a = acc[pos];
-            const int jlo = max(0, (t - W + g.h) / g.h), jhi = min(c.nWin - 1, t / g.h);
+            const int jlo = max(0, hsh >= 0 ? (t - W + g.h) >> hsh : (t - W + g.h) / g.h), jhi = min(c.nWin - 1, hsh >= 0 ? t >> hsh : t / g.h);
             for (int j = jlo; j <= jhi; j++) {
                 const int i = t - j * g.h;
                 if (i >= 0 && i < W) a += gainVoc * (double)o[(size_t)j * W + i] * d.vocWin[i];
@@ -900,7 +936,9 @@ void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &
                   void (*afterIngest)(void *), void *hookArg)
 {
     const VpV2 &v = v_;
-    V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_in);
+    // the staged stretch of the ring through LDS when two channels of it fit beside the kernel's static LDS (else straight from the ring)
+    const int span = (c.nWin - 1) * g.h + g.W, spanLds = (c.nWin > 0 && (size_t)2 * span * sizeof(float) <= 40 * 1024) ? ((span + 3) & ~3) : 0;
+    V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), (size_t)2 * spanLds * sizeof(float), g, c, d, v, d_in, spanLds);
     if (afterIngest) afterIngest(hookArg);
     v2_launch_middle(g, c, d, v, st);
     V2_LAUNCH(vp_k_v2_ola, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_out);
