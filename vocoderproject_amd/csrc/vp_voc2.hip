@@ -14,8 +14,8 @@
 //   autocorr   lane = window, wave = 64 windows x L lags (biaisedAutoCorr, LPC.cpp:44-97)            -> r  [NW][.]
 //   levinson   lane = window (levinsonDurbin, LPC.cpp:107-148)                                       -> a  [NW][.]
 //   fir        lane = window, wave = 64 windows x 64 outputs (filterFIR, VocoderProcess.cpp:235-251) -> e  [NW][W]
-//   energy     lane = window: sum e^2 in order, 10-deep histories, gain (:250, :264-275)              -> g  [NW]
-//   iir        EXACT: lane = window, the reference's chain (:277-286); FAST: wave = window, block form -> out [NW][W]
+//   energy     EXACT: lane = window: sum e^2 in order (:250); FAST: the slices' sums, added up by the recursion kernel's rows
+//   iir        10-deep histories, gain (:264-275); EXACT: lane = window, the reference's chain (:277-286); FAST: wave = window, block form -> out [NW][W]
 //   ola        workgroup = stream: gainVoc * out * stWindow added in window order (:291-295) [+ emit]
 //
 // Every kernel is bit-identical to vp_k_vocoder in VP_IIR_EXACT mode (tests/test_gpu_round2.py); in VP_IIR_FAST mode the
