@@ -690,7 +690,7 @@ def main():
         q.set_iir_mode(args.iir)
         xl = make_streams(S_, N_ * 4, fs=fs_, first_stream=rank * S_, device=dev).view(S_, 3, 4, N_).permute(2, 0, 1, 3).contiguous()
         yl = torch.empty((S_, 2, N_), dtype=torch.float32, device=dev)
-        dtl_ = region(lambda i: q.process_device(xl[i % 4], yl, stream.cuda_stream), steps_, 3)
+        dtl_ = region(lambda i: q.process_device(xl[i % 4], yl, stream.cuda_stream), steps_, 12)
         (dtl_,) = max_over_ranks(dtl_)
         out_ = {"workload": what, "value": (S_ * N_ // hop_) * steps_ * n_gpus / dtl_, "unit": "frames/s", "frame_hop": hop_,
                 "ms_per_step": dtl_ / steps_ * 1e3, "steps": steps_, "streams_per_gpu": S_, "mode": mode_, "iir_mode": args.iir,
@@ -722,7 +722,7 @@ def main():
         return out_
 
     cfg2 = cfg3 = cfg4 = None
-    k4 = max(40, args.steps // 4)                      # (a leg is milliseconds: long enough for a stable figure whatever --steps is)
+    k4 = max(120, args.steps // 2)                     # (a leg is tens of milliseconds: long enough for a stable figure whatever --steps is)
     if not args.single_mode and not args.cfg5 and BPS == 1:
         if not (mode == "voc" and args.lpc_voice == 24):
             cfg2 = {"window_512_128": leg("configs[2]: 256 streams, vocoder, lpcVoice 24, the reference's 512/128 window", "voc", 256, 44100.0, 1024, 256,
@@ -732,7 +732,7 @@ def main():
         if not (mode == "both" and S == 1024):
             cfg3 = leg("configs[3] per GPU: 1024 streams, pitch corrector + vocoder", "both", 1024, 44100.0, 1024, 256, None, {}, k4, with_exchange=True, blocks=8)
         cfg4 = leg("configs[4] per GPU: 512 streams @48 kHz, 2048-pt frames hop 512, orders 48/48/30, pitch corrector + vocoder", "both", 512,
-                   48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(32, args.steps // 6))
+                   48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(64, args.steps // 3))
 
     total_frames = frames_per_step_gpu * args.steps * n_gpus
     value = total_frames / dt
