@@ -733,13 +733,70 @@ __device__ __forceinline__ float v2_mb_src(const VpGeom &g, const VpCall &c, con
     return in[(((size_t)bl * g.S + s) * 3 + ch) * g.N + off];
 }
 
-__global__ __launch_bounds__(256) void vp_k_v2_mb_ingest_stage(VpGeom g, VpCall c, VpDev d, VpV2 v, VpV2MB mb, const float *__restrict__ in)
+// x / d for x >= 0 and a wave-uniform d that is usually a power of two (hop, block size): a shift then, else the division -- a division
+// by a run-time value is ~25 vector instructions, and the multi-block kernels did several per sample
+struct V2Div {
+    int d, sh;
+    __device__ __forceinline__ int operator()(int x) const { return sh >= 0 ? x >> sh : x / d; }
+};
+__device__ __forceinline__ V2Div v2_div(int d) { V2Div r; r.d = d; r.sh = (d > 0 && (d & (d - 1)) == 0) ? __builtin_ctz(d) : -1; return r; }
+
+// voice and side-chain channel 0 at logical index L >= 0 (v2_mb_src for both, one index computation)
+__device__ __forceinline__ void v2_mb_src2(const VpGeom &g, const VpCall &c, const VpDev &d, const float *__restrict__ in, int s, const V2Div &divN, int L,
+                                           float &a, float &b)
 {
+    if (L < g.latency) {
+        const int p = ring_pos(c.currCounter, L, g.inSize);
+        a = d.voiceRing[(size_t)s * g.inSize + p];
+        b = d.synthRing[(size_t)s * 2 * g.inSize + p];
+    } else {
+        const int bl = divN(L - g.latency), off = (L - g.latency) - bl * g.N;
+        const float *q = in + (((size_t)bl * g.S + s) * 3) * g.N + off;
+        a = q[0];
+        b = q[g.N];
+    }
+}
+
+// chunkWin > 0 (round 4; the launch grants dynamic LDS for two channels of (chunkWin - 1) hop + W samples): the windows are staged
+// chunkWin at a time through LDS -- their stretch of the signal read once with coalesced loads, the tiles built from there (see
+// v2_stage_block) -- instead of eight gathers with an index division each per tile entry (247 -> 212 us for 8 blocks of 1024 streams).
+__global__ __launch_bounds__(256) void vp_k_v2_mb_ingest_stage(VpGeom g, VpCall c, VpDev d, VpV2 v, VpV2MB mb, const float *__restrict__ in, int chunkWin)
+{
+    extern __shared__ float v2_stage_lds[];
     __shared__ int gl[V2_MB_MAX];
     const int s = vp_stream(d), b = blockIdx.x, tid = threadIdx.x;
     const int NWs = c.nWin;                                                 // windows per stream in this launch
     // a. every window of the launch into the tiles, and the ring-held part of the dry paths' samples
     const int W4 = (g.W + 3) >> 2;
+    const V2Div divN = v2_div(g.N);
+    if (chunkWin > 0) {
+        const int cap = (chunkWin - 1) * g.h + g.W;                         // floats per channel in LDS
+        for (int k0 = 0; k0 < NWs; k0 += chunkWin) {
+            const int nk = min(chunkWin, NWs - k0), span = (nk - 1) * g.h + g.W, Lb = mb.vStart[0] + k0 * g.h;
+            for (int t = tid; t < span; t += blockDim.x) v2_mb_src2(g, c, d, in, s, divN, Lb + t, v2_stage_lds[t], v2_stage_lds[cap + t]);
+            __syncthreads();
+            // threads as (row ti, window tk): windows fastest, KW = a power of two covering the chunk's windows (at most 64)
+            int ksh = 0;
+            while ((1 << ksh) < min(nk, 64)) ksh++;
+            const int tk = tid & ((1 << ksh) - 1), ti = tid >> ksh, rows = (int)blockDim.x >> ksh;
+            for (int i4 = ti; i4 < W4; i4 += rows)
+                for (int k = tk; k < nk; k += 1 << ksh) {
+                    const int w = b * NWs + k0 + k, q0 = k * g.h + 4 * i4;
+                    float a4[4], b4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const bool inw = 4 * i4 + u < g.W;
+                        a4[u] = inw ? v2_stage_lds[q0 + u] : 0.0f;
+                        b4[u] = inw ? v2_stage_lds[cap + q0 + u] : 0.0f;
+                    }
+                    float *xv = v.xT + ((((size_t)(w >> 6)) * v.W4p + i4) * 64 + (w & 63)) * 4;
+                    float *xs = xv + (size_t)v.nGroupsMax * v.W4p * 256;
+                    *(float4 *)xv = make_float4(a4[0], a4[1], a4[2], a4[3]);
+                    *(float4 *)xs = make_float4(b4[0], b4[1], b4[2], b4[3]);
+                }
+            __syncthreads();
+        }
+    } else
     for (int t = tid; t < NWs * W4; t += blockDim.x) {
         const int i4 = t / NWs, k = t - i4 * NWs;
         const int w = b * NWs + k;
@@ -804,6 +861,8 @@ __global__ __launch_bounds__(256) void vp_k_v2_mb_ola_emit(VpGeom g, VpCall c, V
     const float *oF = (const float *)v.out + (size_t)wBase * W;
     const double *oD = v.out + (size_t)wBase * W;
     double *pl = d.pLin ? d.pLin + (size_t)s * ((size_t)V2_MB_MAX * g.N + g.outSize) : nullptr;
+    // (round 4, measured and dropped: the run-time divisions of this loop -- ring position, covering windows, block and slab of a
+    // sample -- as shifts / compare-and-subtract: 217.7 -> 229.8 us for 8 blocks of 1024 streams)
     for (int t = tid; t < BN + g.outSize; t += blockDim.x) {
         double val = 0.0;
         if (t < g.outSize) {
@@ -948,7 +1007,11 @@ void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const
                          hipStream_t st)
 {
     const VpV2 &v = v_;
-    V2_LAUNCH(vp_k_v2_mb_ingest_stage, dim3(v.nStreams), dim3(256), 0, g, c, d, v, mb, d_in);
+    // windows per LDS chunk of the stage kernel: two channels of (chunk - 1) hop + W floats within 40 KB (0: straight from memory)
+    int chunkWin = ((40 * 1024 / 8) - g.W) / g.h + 1;
+    chunkWin = (chunkWin >= 2 && g.W <= 40 * 1024 / 8) ? std::min(chunkWin, 64) : 0;
+    const size_t ldsStage = chunkWin ? (size_t)2 * ((chunkWin - 1) * g.h + g.W) * sizeof(float) : 0;
+    V2_LAUNCH(vp_k_v2_mb_ingest_stage, dim3(v.nStreams), dim3(256), ldsStage, g, c, d, v, mb, d_in, chunkWin);
     v2_launch_middle(g, c, d, v, st);
     V2_LAUNCH(vp_k_v2_mb_ola_emit, dim3(v.nStreams), dim3(256), (size_t)g.outSize * sizeof(double), g, c, d, v, mb, d_in, d_out);
 }
