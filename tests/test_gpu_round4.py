@@ -332,6 +332,28 @@ def test_single_precision_stft_round_trip_against_numpy(F, hop, T):
     assert np.abs(y64 - y).max() < 4e-6 and not np.array_equal(y64, y)
 
 
+def test_stft_precision_switch_through_the_c_abi():
+    """vp_stft_set_precision / vp_stft_get_precision: argument checking, default, and that the phase-vocoder stage ignores the switch (its
+    phases accumulate over the whole stream: double in either setting -- same bits)."""
+    import ctypes as C
+    import torch
+    from vocoderproject_amd import StftRoundTrip
+    st = StftRoundTrip(3, 1024 * 10, 1024, 256)
+    L = st.L
+    assert L.vp_stft_get_precision(st.h) == 0 and st.precision == "f64"                    # VP_STFT_F64 is the default
+    assert L.vp_stft_set_precision(st.h, 2) != 0 and L.vp_stft_set_precision(None, 1) != 0  # invalid value / null handle
+    assert L.vp_stft_get_precision(st.h) == 0
+    x = torch.randn((3, 1024 * 10), dtype=torch.float32, device="cuda") * 0.1
+    y64, y32 = torch.empty_like(x), torch.empty_like(x)
+    st.pitch_shift(x, y64, 5.0)
+    st.set_precision("f32")
+    assert L.vp_stft_get_precision(st.h) == 1
+    st.pitch_shift(x, y32, 5.0)
+    torch.cuda.synchronize()
+    assert torch.equal(y64, y32)
+    st.close()
+
+
 def test_stft_rejects_frame_lengths_the_fused_kernel_is_not_built_for():
     from vocoderproject_amd import StftRoundTrip, VpError
     for F, hop in ((512, 128), (4096, 1024), (1024, 1024), (1024, 48), (2048, 96)):
