@@ -21,3 +21,4 @@ def test_fft_exchange_layouts_are_exact_and_conflict_free():
     assert m and [int(x) for x in m.groups()] == [1, 1, 1, 1], out          # fp64: ds_write_b128 / ds_read_b128 groups
     m = re.search(r"f32 layout: fft512 err ([0-9.eE+-]+) worst bank multiplicity .* (\d+)\s*$", out, re.M)
     assert m and float(m.group(1)) < 1e-10 and int(m.group(2)) == 1, out      # f32: ds_write_b64 / ds_read_b64 groups
+    assert "exchange 1 in registers: transposition ok" in out, out            # the permlane / DPP stages of fft_exchange1_regs

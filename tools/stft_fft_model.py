@@ -147,3 +147,24 @@ def fft512_f32_layout(xin):
 xin=rng.standard_normal(512)+1j*rng.standard_normal(512)
 o32,c32=fft512_f32_layout(xin)
 print("f32 layout: fft512 err",np.abs(o32-np.fft.fft(xin)).max(),"worst bank multiplicity (ds_write_b64 / ds_read_b64 groups)",c32)
+
+# ---- (4) exchange 1 in registers (fft_exchange1_regs, csrc/vp_fft.inc): the transposition register index <-> lane bits 3..5 as three
+# butterfly stages -- v_permlane32_swap on register pairs (j, j + 4), v_permlane16_swap on (j, j + 2), DPP row_ror:8 with bank masks on (j, j + 1)
+def exchange1_regs(z):
+    z=z.copy()
+    def swap32(a,b):
+        A=z[:,a].copy(); B=z[:,b].copy(); z[32:,a]=B[:32]; z[:32,b]=A[32:]
+    def swap16(a,b):
+        A=z[:,a].copy(); B=z[:,b].copy()
+        for r in (1,3): z[16*r:16*r+16,a]=B[16*(r-1):16*r]; z[16*(r-1):16*r,b]=A[16*r:16*r+16]
+    def swap8(a,b):
+        A=z[:,a].copy(); B=z[:,b].copy()
+        for r in range(4): z[16*r+8:16*r+16,a]=B[16*r:16*r+8]; z[16*r:16*r+8,b]=A[16*r+8:16*r+16]
+    for j in range(4): swap32(j,j+4)
+    for j in range(8):
+        if not (j&2): swap16(j,j+2)
+    for j in range(0,8,2): swap8(j,j+1)
+    return z
+zz=np.arange(512.).reshape(64,8); zt=exchange1_regs(zz)
+okx=all(zt[l,m0]==zz[(l&7)+8*m0,l>>3] for l in range(64) for m0 in range(8))
+print("exchange 1 in registers: transposition", "ok" if okx else "WRONG")

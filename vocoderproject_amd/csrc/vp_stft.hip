@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
         }
         request(rd + 1);
         if (live) {
-            fft512(z, xb, L);
+            fft512_rx(z, xb, L);
             rfft_split(z, xb, lane, (const d2 *)ws, X);
             if (MAG) {                                                         // |X[k]|, k <= N, natural order
                 float *m = A.mag + ((size_t)s * A.nFrames + f) * (N + 1);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
         if (live) {
             // ---- merge (the inverse of the split), scaled by c = overlap-add normalisation / N, and conjugated for the inverse transform
             rfft_merge_conj(z, xb, lane, (const d2 *)ws, X, A.c);
-            fft512(z, xb, L);                                                  // y = FFT(conj Z'): x'[2n] = Re y, x'[2n + 1] = -Im y (1/N is in c)
+            fft512_rx(z, xb, L);                                                  // y = FFT(conj Z'): x'[2n] = Re y, x'[2n + 1] = -Im y (1/N is in c)
             wave_sync();
 #pragma unroll
             for (int r = 0; r < 8; r++) slot[lane + 64 * r] = f2{(float)(z.re[r] * wa[r].x), (float)(-(z.im[r] * wa[r].y))};
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused2k(VpStftArgs A)
                 e.re[r] = (double)v.x * w0.x; e.im[r] = (double)v.y * w0.y;
                 o.re[r] = (double)v.z * w1.x; o.im[r] = (double)v.w * w1.y;
             }
-            fft512(e, xb, L, tw1p, tw2p);
-            fft512(o, xb, L, tw1p, tw2p);
+            fft512_rx(e, xb, L, tw1p, tw2p);
+            fft512_rx(o, xb, L, tw1p, tw2p);
             double hr[8], hi[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {                                      // radix-2 on top: lo = E + W^k' O (kept in e), hi = E - W^k' O
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused2k(VpStftArgs A)
                 e.re[q] += hr[q]; e.im[q] += hi[q];
                 o.re[q] = __builtin_fma(dr, wtop[q].x, -(di * wtop[q].y)); o.im[q] = __builtin_fma(dr, wtop[q].y, di * wtop[q].x);
             }
-            fft512(e, xb, L, tw1p, tw2p);                                      // y[2k'] ...
-            fft512(o, xb, L, tw1p, tw2p);                                      // ... and y[2k' + 1], k' = lane + 64 r: x'[2n] = Re y[n], x'[2n + 1] = -Im y[n]
+            fft512_rx(e, xb, L, tw1p, tw2p);                                      // y[2k'] ...
+            fft512_rx(o, xb, L, tw1p, tw2p);                                      // ... and y[2k' + 1], k' = lane + 64 r: x'[2n] = Re y[n], x'[2n + 1] = -Im y[n]
             wave_sync();
 #pragma unroll
             for (int r = 0; r < 8; r++) {
