@@ -168,10 +168,12 @@ __global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, 
 // ONE fused multiply-add tmp[n] * (x w)[n+m] instead of two multiplies and an add -- 2.2x fewer vector instructions per trip.  The
 // reference's association ((x[n] w[n]) x[n+m]) w[n+m] and its two roundings per term are given up: tolerance-mode arithmetic.
 // V2_AC_WAVES wavefronts (consecutive 64-window groups, the same lags) per workgroup (round 4).  A workgroup's wavefronts are dealt to
-// the CU's four SIMDs in turn; single-wavefront workgroups are not: the 896 of them this kernel is at 1024 streams left some of the 1024
-// SIMDs with two of these issue-bound wavefronts and others with none, and the kernel lasted as long as the doubly loaded SIMDs --
-// 37.9 us against 26.1 us for the same wavefronts four to a workgroup (with its loads replaced by constants the old form still took
-// 30 us: that is how it was found).  The pipeline's other lane-per-window kernels were measured the same way and stay one wavefront
+// the CU's four SIMDs in turn.  Single-wavefront workgroups are spread just as evenly on an idle chip -- but not right behind a kernel of
+// big workgroups (tools/ubench_placement.hip reproduces it: 41.5 against 25.5 us), and with both processes on this kernel follows the pitch
+// kernel: the 896 one-wavefront workgroups it is at 1024 streams left some of the 1024 SIMDs with two of these issue-bound wavefronts
+// and others with none, and the kernel lasted as long as the doubly loaded SIMDs -- 37.9 us against 26.1 us for the same wavefronts
+// four to a workgroup (vocoder alone, i.e. behind the stage kernel: 28.2 against 26.7 us; with its loads replaced by constants the old
+// form still took 30 us: that is how it was found).  The pipeline's other lane-per-window kernels were measured the same way and stay one wavefront
 // per workgroup: they are latency-bound (two of their wavefronts on a SIMD overlap) or have several wavefronts per SIMD anyway --
 // vp_k_v2_iir_fast 31.1 -> 30.8 us, vp_k_v2_fir2 16.8 -> 17.0, vp_k_v2_levinson2 12.3 -> 12.4, vp_k_v2_iir_exact<40> 157 -> 162.
 #define V2_AC_WAVES 4
