@@ -19,10 +19,10 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libvp_amd.so")
 SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_stft.hip", "vp_capi.hip"]
-PARTS = ["vp_fft.inc", "vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc"]      # included by vp_kernels.hip
+PARTS = ["vp_fft.inc", "vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc", "vp_pitch_ws.inc"]      # included by vp_kernels.hip
 DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h", "vp_stft.h", "vp_fft32.inc"]
 ARCH = "gfx950"
-NUM_TUS = 5          # groups of kernels in vp_kernels.hip (VP_TU)
+NUM_TUS = 6          # groups of kernels in vp_kernels.hip (VP_TU)
 
 
 def hipcc():
@@ -53,6 +53,28 @@ def needs_build():
 
 LIB_STAMPS = os.path.join(HERE, "libvp_amd_stamps.so")
 LIB_POISON = os.path.join(HERE, "libvp_amd_poison.so")
+
+
+CACHE_CAP_BYTES = 200 << 20
+
+
+def prune_cache(cap=CACHE_CAP_BYTES):
+    """Least-recently-used objects go until the object cache is below `cap` (it once grew to 1.2 GB of experiment objects)."""
+    cache = os.path.join(HERE, ".build_cache")
+    try:
+        ents = [(os.path.getmtime(os.path.join(cache, f)), os.path.getsize(os.path.join(cache, f)), os.path.join(cache, f))
+                for f in os.listdir(cache)]
+    except OSError:
+        return
+    total = sum(e[1] for e in ents)
+    for _, size, path in sorted(ents):
+        if total <= cap:
+            break
+        try:
+            os.remove(path)
+            total -= size
+        except OSError:
+            pass
 
 
 def build(force=False, verbose=False, stamps=False, poison=False):
@@ -108,8 +130,10 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             cache = os.path.join(HERE, ".build_cache")
             os.makedirs(cache, exist_ok=True)
             cached = os.path.join(cache, os.path.basename(obj) + "." + hsh.hexdigest()[:20])
-            if os.path.exists(cached) and not os.environ.get("VP_NO_OBJ_CACHE"):
+            # force=True (what __graft_entry__.build() passes) COMPILES: the cache only serves the development loop
+            if os.path.exists(cached) and not force and not os.environ.get("VP_NO_OBJ_CACHE"):
                 shutil.copy(cached, obj)
+                os.utime(cached)                                   # (LRU: served objects are the young ones)
                 return obj
             if verbose:
                 print(" ".join(cmd))
@@ -121,6 +145,7 @@ def build(force=False, verbose=False, stamps=False, poison=False):
 
         with ThreadPoolExecutor(len(jobs)) as ex:
             objs = list(ex.map(compile_one, jobs))
+        prune_cache()
         link = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", lib]
         if verbose:
             print(" ".join(link))

@@ -168,6 +168,20 @@ static PitchPlan pitch_plan(const vp_handle *h, bool fast, int nBlocks)
     if (com) return fast ? VP_PLAN(vp_k_pitch_fast_c, lds) : VP_PLAN(vp_k_pitch_c, lds);
     return fast ? VP_PLAN(vp_k_pitch_fast, lds) : VP_PLAN(vp_k_pitch, lds);
 }
+// Round 5: the wave-specialised kernel (vp_pitch_ws.inc) serves single-block launches of the common-case geometry with 1024-sample
+// frames (the plugin's own at 44.1 kHz) whenever its carve -- the whole block's voice window, two frames' buffers, the background's
+// scratch -- fits the CU's LDS; one workgroup per CU, so batches that the register-light builds would pack two to a CU keep those.
+// VP_NO_WS=1 (diagnostic): the phase kernels everywhere, for same-box A/B runs.
+static bool pitch_ws_ok(const vp_handle *h, bool fast, int nBlocks, int nSteps)
+{
+    static const bool off = getenv("VP_NO_WS") != nullptr;
+    const VpGeom &g = h->g;
+    if (off || nBlocks != 1 || nSteps <= 0 || !pitch_common(h) || pitch_lite(h, fast) || g.F != 1024 || g.C > 512 || g.cpf < 2) return false;
+    if ((size_t)(g.toKeep + g.F + (nSteps - 1) * g.C) >= (size_t)g.inSize) return false;
+    if (nSteps + (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXI || (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXS) return false;
+    return vp_pitch_ws_lds_bytes(g, nSteps) <= h->ldsMax;
+}
+
 // The certified cross-correlation YIN of the full-register common-case builds (vp_k_pitch_c, vp_k_pitch_fast_c, vp_k_pitch_fast_multi_c)
 // evaluates its cross-correlations by FFT (vp_pitch.inc xcorr_fft_wave; they carry no other form): one wavefront and one exchange
 // buffer per forward transform, two per 512-sample segment of the frame.  0: the launch does not use it.
@@ -184,7 +198,9 @@ static size_t pitch_xfft_lds(const vp_handle *h) { return vp_pitch_fft_lds_bytes
 extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
-    return pitch_plan(h, h->iirMode == VP_IIR_FAST, 1).name;
+    const bool fast = h->iirMode == VP_IIR_FAST;
+    if (pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C)) return fast ? "vp_k_pitch_ws" : "vp_k_pitch_ws_x";
+    return pitch_plan(h, fast, 1).name;
 }
 
 // vp_k_vocoder_lite (FAST IIR only, <= 128 VGPRs): above 256 streams, with at most four window slots so that two
@@ -622,6 +638,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
                              (const void *)vp_k_pitch_front, (const void *)vp_k_pitch_front_fast,
+                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x,
                              (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -1001,6 +1018,12 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                     cp.fftOff = (int)off; cp.fftWaves = fw; plan.lds = off + pitch_xfft_lds(h);
                 }
                 cp.ldsBytes = (int)plan.lds;
+                if (pitch_ws_ok(h, cp.iirFast != 0, nBlocks, cp.nSteps)) {
+                    // the wave-specialised kernel: its own carve (the accumulator slice and the FFT's tables are part of it)
+                    cp.ldsAcc = 1; cp.fftOff = 0; cp.fftWaves = 0; cp.front = 0;
+                    cp.ldsBytes = (int)vp_pitch_ws_lds_bytes(g, cp.nSteps);
+                    hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_ws : vp_k_pitch_ws_x, dim3(co.n), dim3(512), (size_t)cp.ldsBytes, st, g, cp, d, d_in, d_out);
+                } else
                 hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
             }
         }
@@ -1564,6 +1587,7 @@ extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int fram
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    if (vp_stft_prepare_device() != hipSuccess) return VP_ERR_HIP;          // per handle and device (hipFuncSetAttribute is per device)
     vp_stft *p = new vp_stft();
     p->device = device; p->F = frame_len; p->hop = hop; p->S = n_streams; p->T = n_samples;
     p->nFrames = (n_samples - frame_len) / hop + 1;

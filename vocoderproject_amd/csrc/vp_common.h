@@ -162,6 +162,60 @@ VP_HD static inline size_t vp_pitch_front_lds_bytes(const VpGeom &g)
 // and history (PitchLds::pend), placed behind vp_pitch_lds_bytes()
 VP_HD static inline size_t vp_pitch_acc_lds_bytes(const VpGeom &g) { return ((size_t)g.N + g.C + 1 + g.C + 128) * sizeof(double) + 16; }
 
+// ---- the wave-specialised pitch kernel (vp_pitch_ws.inc): control block and LDS carve, shared with the host's plan ----
+#define WS_MAXI 24                      // chunk instances per block (steps + frame starts)
+#define WS_MAXS 8                       // frame starts per block
+#define WS_NBG 4                        // background wavefronts
+
+struct WsCtl {                          // ints in LDS, zeroed by thread 0 in the prologue
+    int psDone;                         // instances whose producer work is complete
+    int fillTurn;                       // instances whose windowed add is complete (the reference's order of additions)
+    int bgPub, bgAdopt;                 // frame starts published by the background / adopted by the producers
+    int prodBar, bgBar;                 // software barriers of the two groups (monotone counters)
+    int xcDone, zeroDone, pDone, acDone, lpcDone, pickState, pickDone;   // background-internal, generation = start index + 1
+    int pubMode;                        // of the published start: 0 gate closed, 1 no analysis marks, 2 full
+    int lpcZ[2];                        // per parity: levinsonDurbin took the |r0| < 1e-9 branch
+    int nInst, nStart;
+    int instStep[WS_MAXI], instK[WS_MAXI], instPar[WS_MAXI], instStart[WS_MAXI], instMode[WS_MAXI];
+    int startStep[WS_MAXS], startPar[WS_MAXS], startNeed[WS_MAXS];
+    int ishareBG[4], ishareP[4];
+    int fftFlag[4];
+};
+
+
+// dynamic LDS of the kernel: see the carve in pitch_ws_body (the host's vp_pitch_ws_lds_bytes mirrors it)
+struct WsCarve {
+    int xs, eF, fr, qtab, htab, P, dY, gtab, r, aPrev, hp, aF, xp, hist, tw, oA, st, ctl, end;   // offsets in doubles
+};
+VP_HD static inline int ws_even(int v) { return (v + 1) & ~1; }
+VP_HD static inline WsCarve ws_carve(const VpGeom &g, int nSteps)
+{
+    WsCarve c;
+    int o = 0;
+    c.xs = o;    o += ws_even(g.toKeep + g.F + (nSteps - 1) * g.C + 4);
+    c.eF = o;    o += ws_even(g.eLen);
+    c.fr = o;    o += 4 * g.F + 2048;                                          // oE[0] yF[0] | 2 exchange buffers | yF[1] oE[1]
+    c.qtab = o;  o += ws_even(2 * g.tauMax + 4);
+    c.htab = o;  o += ws_even(2 * g.tauMax + 2);
+    c.P = o;     o += ws_even(g.F + g.tauMax + 2 > 450 ? g.F + g.tauMax + 2 : 450);   // prefix sums; the running sum of the fallback
+    c.dY = o;    o += ws_even(vp_dy_len(g.tauMax) + 1);
+    c.gtab = o;  o += 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2 + 1;
+    o = ws_even(o);
+    c.r = o;     o += 2 * 64;                                                  // per parity: r[0..15], the other half's sums at r[32..47]
+    c.aPrev = o; o += 2 * (VP_ORDER_MAX + 1 + 1);                              // per parity: Levinson-Durbin's output
+    c.hp = o;    o += 2 * 128;
+    c.aF = o;    o += 2 * 16;
+    c.xp = o;    o += 64;
+    c.hist = o;  o += 2 * 16;
+    c.tw = o;    o += 2 * VP_FFT_TW_D2;
+    c.oA = o;    o += ws_even(g.N + g.C + 1);
+    c.st = o;    o += 3 * ((int)(sizeof(VpPitchState) + 15) / 16 * 2);
+    c.ctl = o;   o += ((int)sizeof(WsCtl) + 7) / 8;
+    c.end = ws_even(o);
+    return c;
+}
+VP_HD static inline size_t vp_pitch_ws_lds_bytes(const VpGeom &g, int nSteps) { return (size_t)ws_carve(g, nSteps).end * sizeof(double); }
+
 // doubles of LDS one vocoder wavefront needs for a window of length W (see vp_k_vocoder)
 VP_HD static inline size_t voc_wave_doubles(int W)
 {

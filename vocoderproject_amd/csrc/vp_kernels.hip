@@ -19,12 +19,12 @@
 // The kernels are template instantiations of two large bodies; the build compiles this file several times side by side,
 // each translation unit keeping one group of them (-DVP_TU=k; 0 or undefined: all of them, e.g. for -S listings).
 //   1: ingest/gate, vocoder, emit   2: vp_k_pitch   3: vp_k_pitch_fast   4: vp_k_pitch_multi, vp_k_pitch_fast_multi
-//   5: vp_k_pitch_lite, vp_k_pitch_lite_fast
+//   5: vp_k_pitch_lite, vp_k_pitch_lite_fast   6: vp_k_pitch_ws, vp_k_pitch_ws_x (vp_pitch_ws.inc)
 #ifndef VP_TU
 #define VP_TU 0
 #endif
 #define VP_TU_HAS(K) (VP_TU == 0 || VP_TU == (K))
-#define VP_NUM_TUS 5
+#define VP_NUM_TUS 6
 
 #define WAVE 64
 
@@ -332,3 +332,5 @@ __global__ __launch_bounds__(256) void vp_k_emit(VpGeom g, VpCall c, VpDev d, fl
     emit_block(g, c, d, out);
 }
 #endif
+
+#include "vp_pitch_ws.inc"       // K2w: the wave-specialised pitch corrector (round 5)

@@ -29,3 +29,5 @@ size_t vp_stft_lds_bytes(int F, int hop, int f32 = 0);
 // enqueues the fused kernel (grid = runs x streams); returns hipGetLastError()
 hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStream_t st);
 int vp_stft_supported(int F, int hop);
+// once per handle, on the handle's device (current device): the dynamic-LDS ceiling of the builds that need more than 64 KB
+hipError_t vp_stft_prepare_device();

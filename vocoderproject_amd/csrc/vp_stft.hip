@@ -574,13 +574,15 @@ __global__ __launch_bounds__(64 * NWV, 3) void vp_k_stft_fused2k32(VpStftArgs A)
     }
 }
 
+// hipFuncSetAttribute acts on the CURRENT device: every handle raises the phase-vocoder build's dynamic-LDS ceiling on its own device
+// at create (vp_stft_create, behind hipSetDevice), and a failure is the caller's VP_ERR_HIP -- not a process-wide flag set once.
+hipError_t vp_stft_prepare_device()
+{
+    return hipFuncSetAttribute((const void *)vp_k_stft_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+}
+
 hipError_t vp_stft_launch(const VpStftArgs &a, int nStreams, int nRuns, hipStream_t st)
 {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)vp_k_stft_fused<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr = true;
-    }
     const size_t lds = vp_stft_lds_bytes(a.F, a.hop, a.f32);
     const dim3 grid(nRuns, nStreams), block(64 * NWV);
     if (a.f32 && a.F == 2048) {
