@@ -266,6 +266,8 @@ int vp_read_ub_counters(vp_handle *h, long out[5]);
  * sums / LPC coefficients / grain table) ran out -- always 0; anything else is a bug.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
  * certified / handed to the reference's arithmetic. */
 int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
+/* Diagnostic build only: per-wavefront timers of the wave-specialised pitch kernel, [4 block types][16 wavefronts][8 slots] (tools/ws_stamps.py). */
+int vp_debug_read_ws_stamps(vp_handle *h, unsigned long long out[512], int reset);
 /* Diagnostic build only: ticks each of the first n streams' workgroups spent inside the pitch kernel (which stream paces a launch). */
 int vp_debug_read_stream_ticks(vp_handle *h, unsigned long long *out, int n, int reset);
 

@@ -6,6 +6,7 @@ and the bounded-wait timeout counter (must stay 0).
     python tools/ws_ab.py [--streams 256] [--blocks 48]
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -50,7 +51,7 @@ def child(a):
             stamps = [round(v * 100.0) for v in p.debug_stamps(reset=False)]
             np.save(os.path.join(a.out, f"y_{iir}_{yin}.npy"), y)
             res[f"{iir}_{yin}"] = dict(kernel=name, timeouts=[int(stamps[i]) for i in (59, 60, 61)], cert=[int(stamps[62]), int(stamps[63])],
-                                        states=[hash(s) for s in states], rms=float(np.sqrt((y.astype(np.float64) ** 2).mean())))
+                                        states=[hashlib.sha256(s.encode()).hexdigest()[:16] for s in states], rms=float(np.sqrt((y.astype(np.float64) ** 2).mean())))
             if yin == "xcorr":
                 U = 16
                 xd = make_streams(S, N * U, device=dev).view(S, 3, U, N).permute(2, 0, 1, 3).contiguous()

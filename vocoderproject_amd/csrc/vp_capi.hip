@@ -178,7 +178,7 @@ static bool pitch_ws_ok(const vp_handle *h, bool fast, int nBlocks, int nSteps)
     const VpGeom &g = h->g;
     if (off || nBlocks != 1 || nSteps <= 0 || !pitch_common(h) || pitch_lite(h, fast) || g.F != 1024 || g.C > 512 || g.cpf < 2) return false;
     if ((size_t)(g.toKeep + g.F + (nSteps - 1) * g.C) >= (size_t)g.inSize) return false;
-    if (nSteps + (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXI || (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXS) return false;
+    if (nSteps + (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXI || (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXS) return false;   // (ws_build_sched's limits, whatever nChunk)
     return vp_pitch_ws_lds_bytes(g, nSteps) <= h->ldsMax;
 }
 
@@ -663,7 +663,8 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.hImp, (size_t)S * 128));
     RC(dev_alloc(h, &d.front, (size_t)S * VP_FRONT_MAX));
     RC(dev_alloc(h, &d.ub, (size_t)5));
-    RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S));        // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks
+    RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S + 512));  // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks, then the
+                                                             // wave-specialised pitch kernel's per-wavefront timers [4 block types][16 wavefronts][8]
     vocWin.resize((size_t)W + 16, 0.0);                                      // (zero padding: vp_k_v2_autocorr fetches whole 8-entry stretches)
     RC(dev_upload(h, &d.vocWin, vocWin));
     RC(dev_upload(h, &d.pitchStWin, pitchSt));
@@ -1022,7 +1023,11 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                     // the wave-specialised kernel: its own carve (the accumulator slice and the FFT's tables are part of it)
                     cp.ldsAcc = 1; cp.fftOff = 0; cp.fftWaves = 0; cp.front = 0;
                     cp.ldsBytes = (int)vp_pitch_ws_lds_bytes(g, cp.nSteps);
-                    hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_ws : vp_k_pitch_ws_x, dim3(co.n), dim3(512), (size_t)cp.ldsBytes, st, g, cp, d, d_in, d_out);
+                    static const int wsWaves = [] { const char *e = getenv("VP_WS_WAVES"); const int v = e ? atoi(e) : 0; return (v >= 8 && v <= 12) ? v : 12; }();   // (diagnostic: 8..12)
+                    VpWsSched sc;
+                    memset(&sc, 0, sizeof sc);
+                    if (!ws_build_sched(g, cp.nChunk0, cp.nSteps, sc)) return fail_hip(h, hipErrorInvalidValue, "pitch schedule");   // (pitch_ws_ok's bounds rule this out)
+                    hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_ws : vp_k_pitch_ws_x, dim3(co.n), dim3(64 * wsWaves), (size_t)cp.ldsBytes, st, g, cp, d, sc, d_in, d_out);
                 } else
                 hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
             }
@@ -1533,6 +1538,17 @@ extern "C" int vp_debug_read_stream_ticks(vp_handle *h, unsigned long long *out,
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->d.dbg + 64, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(h, hipMemset(h->d.dbg + 64, 0, (size_t)h->g.S * sizeof(unsigned long long)));
+    return VP_OK;
+}
+
+extern "C" int vp_debug_read_ws_stamps(vp_handle *h, unsigned long long out[512], int reset)
+{
+    if (!h || !out) return VP_ERR_INVALID_ARG;
+    if (!h->prepared) return VP_ERR_NOT_PREPARED;
+    if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->d.dbg + 64 + h->g.S, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->d.dbg + 64 + h->g.S, 0, 512 * sizeof(unsigned long long)));
     return VP_OK;
 }
 

@@ -173,15 +173,56 @@ struct WsCtl {                          // ints in LDS, zeroed by thread 0 in th
     int bgPub, bgAdopt;                 // frame starts published by the background / adopted by the producers
     int prodBar, bgBar;                 // software barriers of the two groups (monotone counters)
     int xcDone, zeroDone, pDone, acDone, lpcDone, pickState, pickDone;   // background-internal, generation = start index + 1
+    int tDone;                          // starts whose grain half-length T is final (pickT: per parity), for the producers' early Hann staging
+    int pickT[2];
+    int iirDone;                        // FAST: instances whose recursion is complete (the windowed add is another wavefront's)
     int pubMode;                        // of the published start: 0 gate closed, 1 no analysis marks, 2 full
     int lpcZ[2];                        // per parity: levinsonDurbin took the |r0| < 1e-9 branch
-    int nInst, nStart;
-    int instStep[WS_MAXI], instK[WS_MAXI], instPar[WS_MAXI], instStart[WS_MAXI], instMode[WS_MAXI];
-    int startStep[WS_MAXS], startPar[WS_MAXS], startNeed[WS_MAXS];
+    int instMode[WS_MAXI];              // per instance, decided by the producers: 0 nothing, 1 output only, 2 recursion + output
     int ishareBG[4], ishareP[4];
     int fftFlag[4];
 };
 
+// The block's SCHEDULE (PitchProcess.cpp:171-189): per chunk step [Cont of the running frame], then, when a frame starts there,
+// [Start].  It follows from the cohort's counters alone, so the host builds it and hands it over as a kernel argument (scalar
+// loads; thread 0 used to build it in LDS while the workgroup waited at the prologue's barrier).  Frames alternate between the two
+// parity buffers; the frame in flight at the block's entry has parity 0.  A SEGMENT is a maximal run of instances of one frame
+// inside the block: the producers take a segment's residual, grain table and gather pass in one go.
+struct VpWsSched {
+    int nInst, nStart, nSeg;
+    int instStep[WS_MAXI], instK[WS_MAXI], instPar[WS_MAXI], instStart[WS_MAXI];   // instStart: the start's index, or -1 (a Cont chunk)
+    int startStep[WS_MAXS], startPar[WS_MAXS], startNeed[WS_MAXS];                 // startNeed: instances that must have been added to the
+                                                                                    // output before the start's parity buffers are free
+    int segA[WS_MAXS + 1], segB[WS_MAXS + 1];                                       // first and last instance of each segment
+};
+VP_HD static inline bool ws_build_sched(const VpGeom &g, int nChunk0, int nSteps, VpWsSched &sc)
+{
+    int nCh = nChunk0, par = 0, nI = 0, nS = 0, nG = 0;
+    int lastUse[2] = {0, 0};                                                  // instances up to which a parity's buffers are in use
+    for (int t = 0; t < nSteps; t++) {
+        if (nCh != 0) {
+            if (nI >= WS_MAXI) return false;
+            if (nI == 0) { if (nG > WS_MAXS) return false; sc.segA[nG] = 0; sc.segB[nG] = 0; nG++; }   // the frame in flight opens the block
+            sc.instStep[nI] = t; sc.instK[nI] = nCh; sc.instPar[nI] = par; sc.instStart[nI] = -1;
+            sc.segB[nG - 1] = nI;
+            nI++;
+            lastUse[par] = nI;
+        }
+        if (nCh == g.cpf - 1) nCh = 0;
+        if (nCh == 0) {
+            if (nI >= WS_MAXI || nS >= WS_MAXS || nG > WS_MAXS) return false;
+            par ^= 1;
+            sc.instStep[nI] = t; sc.instK[nI] = 0; sc.instPar[nI] = par; sc.instStart[nI] = nS;
+            sc.startStep[nS] = t; sc.startPar[nS] = par; sc.startNeed[nS] = lastUse[par];
+            sc.segA[nG] = nI; sc.segB[nG] = nI; nG++;
+            nI++; nS++;
+            lastUse[par] = nI;
+        }
+        nCh += 1;
+    }
+    sc.nInst = nI; sc.nStart = nS; sc.nSeg = nG;
+    return nI > 0;
+}
 
 // dynamic LDS of the kernel: see the carve in pitch_ws_body (the host's vp_pitch_ws_lds_bytes mirrors it)
 struct WsCarve {
@@ -199,7 +240,7 @@ VP_HD static inline WsCarve ws_carve(const VpGeom &g, int nSteps)
     c.htab = o;  o += ws_even(2 * g.tauMax + 2);
     c.P = o;     o += ws_even(g.F + g.tauMax + 2 > 450 ? g.F + g.tauMax + 2 : 450);   // prefix sums; the running sum of the fallback
     c.dY = o;    o += ws_even(vp_dy_len(g.tauMax) + 1);
-    c.gtab = o;  o += 2 * VP_MARKS + (5 * VP_MARKS + 1) / 2 + 1;
+    c.gtab = o;  o += 2 * VP_MARKS + (6 * VP_MARKS + 1) / 2 + 1;          // the segment's grain table: 2 double + 6 int arrays
     o = ws_even(o);
     c.r = o;     o += 2 * 64;                                                  // per parity: r[0..15], the other half's sums at r[32..47]
     c.aPrev = o; o += 2 * (VP_ORDER_MAX + 1 + 1);                              // per parity: Levinson-Durbin's output

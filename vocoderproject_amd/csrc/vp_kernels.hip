@@ -169,7 +169,9 @@ __device__ __forceinline__ double vp_one()
 // the stream this workgroup serves (see VpDev::streamMap)
 __device__ __forceinline__ int vp_stream(const VpDev &d)
 {
-    return d.streamMap ? d.streamMap[blockIdx.x] : (int)blockIdx.x;
+    // (through readfirstlane: the map's entry is a loaded value, which the compiler takes for lane-varying -- and with it every row
+    // pointer derived from the stream index: 64-bit vector registers carried, or spilled, across the whole kernel)
+    return __builtin_amdgcn_readfirstlane(d.streamMap ? d.streamMap[blockIdx.x] : (int)blockIdx.x);
 }
 
 typedef __attribute__((address_space(3))) VpPitchState lds_state;
@@ -252,7 +254,7 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
     }
     sv = wave_sum(sv);
     ss = wave_sum(ss);
-    __shared__ double red[2][8];
+    __shared__ double red[2][16];
     if ((tid & 63) == 0) { red[0][tid >> 6] = sv; red[1][tid >> 6] = ss; }
     __syncthreads();
     if (tid < 2) {
