@@ -206,6 +206,13 @@ int vp_get_overlap(const vp_handle *h);
  * lpcPitch < 64); ignored otherwise. */
 int vp_set_time_parallel(vp_handle *h, int on);
 int vp_get_time_parallel(const vp_handle *h);
+/* Round 5: which pitch-corrector kernel serves single-block calls of the plugin's own geometry (1024-sample frames, lpcPitch <= 15,
+ * up to 256 streams).  1 (default): vp_k_pitch_ws / vp_k_pitch_ws_x, the WAVE-SPECIALISED kernel (csrc/vp_pitch_ws.inc: every frame
+ * start's yin() / LPC / marks on four background wavefronts beside the running frame's chunks, PitchProcess.cpp:203-271).  0: the
+ * phase kernels (vp_k_pitch_fast_c / vp_k_pitch_c), which also serve every other geometry.  Same output bits either way
+ * (tests/test_gpu_round5.py); the switch exists for that test and for same-box A/B timing (tools/ws_ab.py). */
+int vp_set_wave_specialised(vp_handle *h, int on);
+int vp_get_wave_specialised(const vp_handle *h);
 
 /* How the YIN difference function (PitchProcess.cpp:350-403) and the pitch frame's LPC autocorrelation
  * (LPC.cpp:44-97) are evaluated.

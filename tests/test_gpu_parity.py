@@ -514,9 +514,16 @@ def test_pitch_kernel_build_selection():
     p = BatchVocoderProcessor(vocBool=0)
     assert p.pitch_kernel_name() == ""
     p.prepareToPlay(FS, 1024, 8)
-    assert p.pitch_kernel_name() == "vp_k_pitch_c"               # chunk of 256 samples, lpcPitch 15, tauMax 441: common case
+    assert p.pitch_kernel_name() == "vp_k_pitch_ws_x"            # the plugin's own geometry, up to 256 streams: the wave-specialised kernel (round 5)
     p.set_iir_mode("fast")
-    assert p.pitch_kernel_name() == "vp_k_pitch_fast_c"
+    assert p.pitch_kernel_name() == "vp_k_pitch_ws"
+    p.set_wave_specialised(False)
+    assert p.pitch_kernel_name() == "vp_k_pitch_fast_c"          # chunk of 256 samples, lpcPitch 15, tauMax 441: common case of the phase kernels
+    p.set_iir_mode("exact")
+    assert p.pitch_kernel_name() == "vp_k_pitch_c"
+    w = BatchVocoderProcessor(vocBool=0)
+    w.prepareToPlay(FS, 4096, 8)                                 # sixteen chunk steps per block: their voice window does not fit beside two frames
+    assert w.pitch_kernel_name() == "vp_k_pitch_c"
     g = BatchVocoderProcessor(vocBool=0, lpcPitch=24)            # an order the common-case builds do not cover
     g.prepareToPlay(FS, 1024, 8)
     assert g.pitch_kernel_name() == "vp_k_pitch"

@@ -60,6 +60,7 @@ struct vp_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     double *acc2 = nullptr;
     int overlap = 0, acc2Live = 0;
+    int waveSpec = 1;                           // vp_set_wave_specialised: vp_k_pitch_ws* where they apply (pitch_ws_ok)
     int timeParallel = 0;                       // vp_set_time_parallel: multi-block pitch launches behind the analysis front end (vp_k_pitch_front)
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
@@ -176,10 +177,10 @@ static bool pitch_ws_ok(const vp_handle *h, bool fast, int nBlocks, int nSteps)
 {
     static const bool off = getenv("VP_NO_WS") != nullptr;
     const VpGeom &g = h->g;
-    if (off || nBlocks != 1 || nSteps <= 0 || !pitch_common(h) || pitch_lite(h, fast) || g.F != 1024 || g.C > 512 || g.cpf < 2) return false;
+    if (off || !h->waveSpec || nBlocks != 1 || nSteps <= 0 || !pitch_common(h) || pitch_lite(h, fast) || g.F != 1024 || g.C > 512 || g.cpf < 2) return false;
     if ((size_t)(g.toKeep + g.F + (nSteps - 1) * g.C) >= (size_t)g.inSize) return false;
     if (nSteps + (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXI || (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXS) return false;   // (ws_build_sched's limits, whatever nChunk)
-    return vp_pitch_ws_lds_bytes(g, nSteps) <= h->ldsMax;
+    return vp_pitch_ws_lds_bytes(g, nSteps) + 256 <= h->ldsMax;                 // (+ the kernels' static reduction slots: 384 bytes against the 256 ldsMax leaves)
 }
 
 // The certified cross-correlation YIN of the full-register common-case builds (vp_k_pitch_c, vp_k_pitch_fast_c, vp_k_pitch_fast_multi_c)
@@ -262,6 +263,13 @@ extern "C" int vp_set_time_parallel(vp_handle *h, int on)
     return VP_OK;
 }
 extern "C" int vp_get_time_parallel(const vp_handle *h) { return h ? h->timeParallel : VP_ERR_INVALID_ARG; }
+extern "C" int vp_set_wave_specialised(vp_handle *h, int on)
+{
+    if (!h) return VP_ERR_INVALID_ARG;
+    h->waveSpec = on ? 1 : 0;
+    return VP_OK;
+}
+extern "C" int vp_get_wave_specialised(const vp_handle *h) { return h ? h->waveSpec : VP_ERR_INVALID_ARG; }
 
 extern "C" const char *vp_vocoder_kernel_name(const vp_handle *h)
 {

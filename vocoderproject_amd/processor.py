@@ -108,6 +108,9 @@ def load_library():
     L.vp_debug_alloc_count.restype = C.c_long
     L.vp_set_time_parallel.argtypes = [C.c_void_p, C.c_int]
     L.vp_get_time_parallel.argtypes = [C.c_void_p]
+    if hasattr(L, "vp_set_wave_specialised"):
+        L.vp_set_wave_specialised.argtypes = [C.c_void_p, C.c_int]
+        L.vp_get_wave_specialised.argtypes = [C.c_void_p]
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
     L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vp_set_yin_mode.argtypes = [vp, C.c_int]
@@ -220,6 +223,10 @@ class BatchVocoderProcessor:
     def set_time_parallel(self, on):
         """Multi-block pitch-only calls behind the time-parallel analysis front end (vp_k_pitch_front; off by default, see include/vp_amd.h)."""
         self._chk(self.L.vp_set_time_parallel(self.h, int(bool(on))))
+
+    def set_wave_specialised(self, on):
+        """Single-block calls of the plugin's geometry on the wave-specialised pitch kernel (default) or on the phase kernels (same bits)."""
+        self._chk(self.L.vp_set_wave_specialised(self.h, int(bool(on))))
 
     def set_yin_mode(self, mode):
         """"direct" (default: the reference's sums), "xcorr" (certified cross-correlation form, fused multiply-adds) or "fft" (the same
