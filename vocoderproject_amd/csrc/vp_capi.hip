@@ -177,7 +177,10 @@ static bool pitch_ws_ok(const vp_handle *h, bool fast, int nBlocks, int nSteps)
 {
     static const bool off = getenv("VP_NO_WS") != nullptr;
     const VpGeom &g = h->g;
-    if (off || !h->waveSpec || nBlocks != 1 || nSteps <= 0 || !pitch_common(h) || pitch_lite(h, fast) || g.F != 1024 || g.C > 512 || g.cpf < 2) return false;
+    // (its own geometric conditions: chunks of whole wavefronts up to 512 samples, lpcPitch <= 15 -- the row forms of Levinson-Durbin and of
+    // the recursions --, every lag on one wavefront, two 512-sample segments per frame for the FFT cross-correlation)
+    if (off || !h->waveSpec || nBlocks != 1 || nSteps <= 0 || pitch_lite(h, fast) || g.F != 1024 || (g.C & 63) != 0 || g.C > 512 || g.cpf < 2 ||
+        g.orderPitch > 15 || g.tauMax > 512) return false;
     if ((size_t)(g.toKeep + g.F + (nSteps - 1) * g.C) >= (size_t)g.inSize) return false;
     if (nSteps + (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXI || (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXS) return false;   // (ws_build_sched's limits, whatever nChunk)
     return vp_pitch_ws_lds_bytes(g, nSteps) + 256 <= h->ldsMax;                 // (+ the kernels' static reduction slots: 384 bytes against the 256 ldsMax leaves)
