@@ -1308,10 +1308,14 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     const bool pitchOnly = h->cohorts.size() == 1 && h->cohorts[0].pitchOn && !h->cohorts[0].vocOn;
     // one launch of the serial kernel for all the blocks (state stays on chip between them), behind the time-parallel analysis
     // front end where the geometry allows it; above 256 streams the register-light builds exist for the FAST recursion only
-    if (pitchOnly && n_blocks > 1 && (!pitch_lite(h, fast) || fast))
+    // (round 5: where the wave-specialised kernel serves the geometry, a launch of it per block beats the one-launch phase kernel -- 44.8
+    // against 53.6 us per block at 256 streams -- and a block loop inside it did not pay: 51.4 us with eight wavefronts, 59.8 with twelve,
+    // the loop level makes everything the programs derive from the geometry and the lane live across all of them)
+    const bool wsBlocks = pitchOnly && !h->timeParallel && pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C);
+    if (pitchOnly && n_blocks > 1 && !wsBlocks && (!pitch_lite(h, fast) || fast))
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
     const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;
-    if (!mono && n_blocks > 1) {                               // vocoder-only plan on the batched pipeline: groups of blocks per launch
+    if (!mono && n_blocks > 1 && !wsBlocks) {                  // vocoder-only plan on the batched pipeline: groups of blocks per launch
         int b = 0;
         while (b < n_blocks) {
             const int nb = std::min(n_blocks - b, std::min(V2_MB_MAX, std::max(h->reservedBlocks, 1)));   // groups the reserved scratch holds
