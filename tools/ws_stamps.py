@@ -57,8 +57,9 @@ def main():
             continue
         print(f"--- type {typ}: {n} launches, kernel {v[typ * 128 + 5] / n / 100.0:.1f} us")
         for w in range(NW):
-            if w == 1 and fast:
-                continue                                   # (the windowed-add wavefront: no timers)
+            if w == 1 and fast:                                # (the windowed-add wavefront has no timers: its slots carry wavefront 0's prologue)
+                print(f"  prologue (wave 0)      requests issued: {v[typ * 128 + 8] / n / 100.0:.1f} | consumed: {v[typ * 128 + 9] / n / 100.0:.1f} | barrier passed: {v[typ * 128 + 10] / n / 100.0:.1f}")
+                continue
             names = REC if w < 2 else PROD if w < NW - 4 else (BG0, BG1, BG2, LEAD)[w - (NW - 4)]
             role = "recursion" if names is REC else "producer" if names is PROD else "background" + (" (lead)" if w == NW - 1 else "")
             cells = []

@@ -250,7 +250,7 @@ VP_HD static inline WsCarve ws_carve(const VpGeom &g, int nSteps)
     c.hist = o;  o += 2 * 16;
     c.tw = o;    o += 2 * VP_FFT_TW_D2;
     c.oA = o;    o += ws_even(g.N + g.C + 1);
-    c.st = o;    o += 3 * ((int)(sizeof(VpPitchState) + 15) / 16 * 2);
+    c.st = o;    o += 2 * ((int)(sizeof(VpPitchState) + 15) / 16 * 2);      // the producers' copy of the tracker state, the background's
     c.ctl = o;   o += ((int)sizeof(WsCtl) + 7) / 8;
     c.end = ws_even(o);
     return c;
