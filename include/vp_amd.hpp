@@ -13,9 +13,17 @@
 // buffers from them.  Errors become exceptions carrying the C status code.
 #pragma once
 
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <utility>
+#include <vector>
 
 #include "vp_amd.h"
 
@@ -146,6 +154,135 @@ private:
     }
     vp_handle *h_ = nullptr;
     vp_params p_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// vp::ShardedBatchProcessor -- the batch split over several GPUs of one node from ONE host process.
+//
+// The reference's ownership model is one plugin instance per stream (PluginProcessor.h:69-73: every instance owns its MyBuffer and
+// its two processes); streams share nothing, so a batch shards by stream with no exchange between the shards.  This is the C++-level
+// form of that split: one handle (a BatchVocoderProcessor) per device in `devices`, shard g owning the contiguous streams
+// shardRange(g) -- the same ranges as vocoderproject_amd/dist.py's shard_range (sizes differ by at most one) --, and one persistent
+// worker thread per shard that drives its handle (the C ABI's threading contract: one caller thread per handle), so the shards'
+// uploads, kernels and downloads run side by side.  A call returns when every shard has.  No RCCL is involved: within one
+// process the host buffers are simply addressed per shard.  (Several entries of `devices` may name the same GPU: that is how the
+// helper is tested on a one-GPU box, against one handle, bit for bit.)
+class ShardedBatchProcessor {
+public:
+    explicit ShardedBatchProcessor(const std::vector<int> &devices)
+    {
+        if (devices.empty()) throw Error(VP_ERR_INVALID_ARG, "ShardedBatchProcessor: no devices");
+        for (int dev : devices) shards_.emplace_back(new Shard(dev));
+    }
+    ~ShardedBatchProcessor() = default;                                          // (every shard stops and joins its own worker)
+    ShardedBatchProcessor(const ShardedBatchProcessor &) = delete;
+    ShardedBatchProcessor &operator=(const ShardedBatchProcessor &) = delete;
+
+    int numShards() const { return (int)shards_.size(); }
+    // [first, first + count) of the batch's streams that shard g owns
+    std::pair<int, int> shardRange(int g) const
+    {
+        const int G = numShards(), base = nStreams_ / G, rem = nStreams_ % G;
+        return {g * base + (g < rem ? g : rem), base + (g < rem ? 1 : 0)};
+    }
+    BatchVocoderProcessor &shard(int g) { return shards_[g]->proc; }
+
+    void setParameter(const char *id, float v) { for (auto &sh : shards_) sh->proc.setParameter(id, v); }
+    void setStreamParameter(int stream, const char *id, float v)
+    {
+        const auto o = owner(stream);
+        shards_[o.first]->proc.setStreamParameter(o.second, id, v);
+    }
+    void setPitchShift(double semitones, bool on = true, int stream = -1)
+    {
+        if (stream < 0) { for (auto &sh : shards_) sh->proc.setPitchShift(semitones, on, -1); return; }
+        const auto o = owner(stream);
+        shards_[o.first]->proc.setPitchShift(semitones, on, o.second);
+    }
+    void prepareToPlay(double sampleRate, int samplesPerBlock, int nStreams)      // PluginProcessor.cpp:144, per shard
+    {
+        if (nStreams < numShards()) throw Error(VP_ERR_INVALID_ARG, "ShardedBatchProcessor: fewer streams than shards");
+        nStreams_ = nStreams; N_ = samplesPerBlock;
+        run([&](int g, Shard &sh) { sh.proc.prepareToPlay(sampleRate, samplesPerBlock, shardRange(g).second); });
+    }
+    void prepareExplicit(double sampleRate, int samplesPerBlock, int nStreams, int frameLenPitch, int hopPitch, int wlenVoc, int hopVoc)
+    {
+        if (nStreams < numShards()) throw Error(VP_ERR_INVALID_ARG, "ShardedBatchProcessor: fewer streams than shards");
+        nStreams_ = nStreams; N_ = samplesPerBlock;
+        run([&](int g, Shard &sh) { sh.proc.prepareExplicit(sampleRate, samplesPerBlock, shardRange(g).second, frameLenPitch, hopPitch, wlenVoc, hopVoc); });
+    }
+    // processBlock (:203) on the whole batch: in [streams][3][N] -> out [streams][2][N], host memory; every shard works on its rows
+    void processBlock(const float *in, float *out)
+    {
+        run([&](int g, Shard &sh) { const int lo = shardRange(g).first; sh.proc.processBlock(in + (size_t)lo * 3 * N_, out + (size_t)lo * 2 * N_); });
+    }
+    void processBlock(float *io)                                                  // in place: [streams][3][N]
+    {
+        run([&](int g, Shard &sh) { sh.proc.processBlock(io + (size_t)shardRange(g).first * 3 * N_); });
+    }
+    void processBlockMono(const float *voice, float *out)                         // voice [streams][N] -> out [streams][2][N]
+    {
+        run([&](int g, Shard &sh) { const int lo = shardRange(g).first; sh.proc.processBlockMono(voice + (size_t)lo * N_, out + (size_t)lo * 2 * N_); });
+    }
+    int getLatencySamples() const { return shards_[0]->proc.getLatencySamples(); }
+
+private:
+    struct Shard {
+        BatchVocoderProcessor proc;
+        std::thread worker;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool busy = false, quit = false;
+        std::exception_ptr err;
+        ~Shard()
+        {
+            { std::lock_guard<std::mutex> lk(m); quit = true; }
+            cv.notify_all();
+            if (worker.joinable()) worker.join();
+        }
+        explicit Shard(int dev) : proc(dev)
+        {
+            worker = std::thread([this] {
+                std::unique_lock<std::mutex> lk(m);
+                for (;;) {
+                    cv.wait(lk, [this] { return quit || busy; });
+                    if (quit) return;
+                    try { job(); } catch (...) { err = std::current_exception(); }
+                    busy = false;
+                    cv.notify_all();
+                }
+            });
+        }
+    };
+    // fn(g, shard) on every shard's own thread, side by side; the first exception is rethrown here once all have finished
+    template <class F>
+    void run(F fn)
+    {
+        for (int g = 0; g < numShards(); g++) {
+            Shard &sh = *shards_[g];
+            { std::lock_guard<std::mutex> lk(sh.m); sh.job = [&fn, g, &sh] { fn(g, sh); }; sh.err = nullptr; sh.busy = true; }
+            sh.cv.notify_all();
+        }
+        std::exception_ptr first;
+        for (auto &shp : shards_) {
+            std::unique_lock<std::mutex> lk(shp->m);
+            shp->cv.wait(lk, [&] { return !shp->busy; });
+            if (shp->err && !first) first = shp->err;
+        }
+        if (first) std::rethrow_exception(first);
+    }
+    std::pair<int, int> owner(int stream) const
+    {
+        if (stream < 0 || stream >= nStreams_) throw Error(VP_ERR_INVALID_ARG, "no such stream");
+        for (int g = 0; g < numShards(); g++) {
+            const auto r = shardRange(g);
+            if (stream < r.first + r.second) return {g, stream - r.first};
+        }
+        return {numShards() - 1, 0};
+    }
+    std::vector<std::unique_ptr<Shard>> shards_;
+    int nStreams_ = 0, N_ = 0;
 };
 
 }  // namespace vp

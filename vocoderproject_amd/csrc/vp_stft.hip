@@ -87,6 +87,53 @@ __device__ __forceinline__ void stft_overlap_add(const VpStftArgs &A, const lds_
 
 #define VP_TWO_PI 6.283185307179586476925286766559
 
+// ---- the phase-vocoder stage's elementary functions, in TURNS (round 5) -----------------------------------------------------------
+// The stage kept its phases in radians and called libm: atan2 per bin, sincos of an accumulated phase of up to thousands of radians
+// per bin (the device library's argument reduction for large arguments), nine of each per lane and frame -- 6000 vector instructions
+// per lane and round, four fifths of the kernel's time.  In turns (1 turn = 2 pi) the reduction is a subtraction of rint(), exact, and
+// what is left are three short polynomials (minimax fits on Chebyshev nodes, tools/stft_pv_fit.py; absolute errors below 4e-16 of a
+// turn / of the unit circle).  Same stage, same definition (tests/stft_reference.py keeps radians and numpy's functions: an independent
+// check); the outputs differ at the 1e-13 level.
+__device__ static const double PV_AT[11] = {0.15915494309189532, -0.05305164769729216, 0.031830988616730685, -0.022736420283186426, 0.017683874894479496,
+                                            -0.014468416126674181, 0.012238931495957754, -0.010567969142530591, 0.009050862433965945, -0.006910937165090144,
+                                            0.003350241773092173};                          // atan(r) / (2 pi r) in u = r^2 on [0, tan^2(pi/8)]
+__device__ static const double PV_SN[7] = {6.283185307179581, -41.341702240399435, 81.60524927567752, -76.70585960744309, 42.05867032464745, -15.092818445192446,
+                                           3.7567969372293444};                              // sin(2 pi t) / t in v = t^2 on [0, 1/64]
+__device__ static const double PV_CS[7] = {1.0000000000000002, -19.739208802178528, 64.93939402241888, -85.4568171016908, 60.24462112885379, -26.424298367777688,
+                                           7.810833486309896};                               // cos(2 pi t) in v = t^2 on [0, 1/64]
+// atan2(im, re) / (2 pi), in [-0.5, 0.5]
+__device__ __forceinline__ double pv_phase_turns(double im, double re)
+{
+    const double ax = fabs(re), ay = fabs(im);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    double r = (mx > 0.0) ? mn / mx : 0.0;                                     // in [0, 1]  (atan2(0, 0) = 0)
+    double base = 0.0;
+    if (r > 0.41421356237309503) { r = (r - 1.0) / (r + 1.0); base = 0.125; }  // atan(r) = pi/4 + atan((r - 1) / (r + 1))
+    const double u = r * r;
+    double q = PV_AT[10];
+#pragma unroll
+    for (int i = 9; i >= 0; i--) q = __builtin_fma(q, u, PV_AT[i]);
+    double t = base + q * r;                                                   // in [0, 1/8]
+    if (ay > ax) t = 0.25 - t;
+    if (re < 0.0) t = 0.5 - t;
+    return (im < 0.0) ? -t : t;
+}
+// (sin, cos) of 2 pi t for any finite t
+__device__ __forceinline__ void pv_sincos_turns(double t, double &sn, double &cs)
+{
+    t -= rint(t);                                                              // [-1/2, 1/2], exact
+    const double q = rint(t * 4.0);                                            // the quarter turn, -2 .. 2
+    const double r = t - q * 0.25;                                             // [-1/8, 1/8], exact
+    const double v = r * r;
+    double ps = PV_SN[6], pc = PV_CS[6];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { ps = __builtin_fma(ps, v, PV_SN[i]); pc = __builtin_fma(pc, v, PV_CS[i]); }
+    const double sr = ps * r, cr = pc;
+    const int iq = (int)q & 3;
+    sn = (iq == 0) ? sr : (iq == 1) ? cr : (iq == 2) ? -sr : -cr;
+    cs = (iq == 0) ? cr : (iq == 1) ? -sr : (iq == 2) ? -cr : sr;
+}
+
 // the wavefront's phase-vocoder work arrays (PV builds only)
 struct PvLds {
     lds_f64 *phPrev;           // [NWV + 1][nb]  slot w + 1: frame of wavefront w this round; slot 0: the previous round's last frame
@@ -180,9 +227,10 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
             }
         }
         if (PV) {
-            // ---- phase-vocoder stage.  Bins of this lane: k = 64 q + lane and N - k (q < 4); lane 0 also holds 0, N and N / 2.
+            // ---- phase-vocoder stage, phases in TURNS.  Bins of this lane: k = 64 q + lane and N - k (q < 4); lane 0 also holds 0, N and N / 2.
             const int nb = N + 1;
-            const double expct = VP_TWO_PI / (double)O;                        // nominal phase advance of bin 1 per hop
+            const double invO = 1.0 / (double)O;                               // nominal phase advance of bin 1 per hop, in turns (O a power of two: exact)
+            const double invRatio = 1.0 / A.pvRatio;
             double ph[9];
             int kb[9];
             double mg[9];
@@ -190,10 +238,10 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     kb[2 * q] = 64 * q + lane; kb[2 * q + 1] = N - kb[2 * q];
-                    mg[2 * q] = sqrt(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]); ph[2 * q] = atan2(X.ki[q], X.kr[q]);
-                    mg[2 * q + 1] = sqrt(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]); ph[2 * q + 1] = atan2(X.mi[q], X.mr[q]);
+                    mg[2 * q] = sqrt(X.kr[q] * X.kr[q] + X.ki[q] * X.ki[q]); ph[2 * q] = pv_phase_turns(X.ki[q], X.kr[q]);
+                    mg[2 * q + 1] = sqrt(X.mr[q] * X.mr[q] + X.mi[q] * X.mi[q]); ph[2 * q + 1] = pv_phase_turns(X.mi[q], X.mr[q]);
                 }
-                kb[8] = N / 2; mg[8] = sqrt(X.hr * X.hr + X.hi * X.hi); ph[8] = atan2(X.hi, X.hr);            // lane 0 only
+                kb[8] = N / 2; mg[8] = sqrt(X.hr * X.hr + X.hi * X.hi); ph[8] = pv_phase_turns(X.hi, X.hr);            // lane 0 only
 #pragma unroll
                 for (int e = 0; e < 9; e++) if (e < 8 || lane0) pv.phPrev[(wv + 1) * nb + kb[e]] = ph[e];
             }
@@ -203,9 +251,9 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                 for (int e = 0; e < 9; e++) {
                     if (e == 8 && !lane0) continue;
                     const int k = kb[e];
-                    double d = ph[e] - pv.phPrev[wv * nb + k] - (double)k * expct;
-                    d -= VP_TWO_PI * rint(d * (1.0 / VP_TWO_PI));              // the unwrap: deviation from the nominal advance in (-pi, pi]
-                    pv.ana[k] = d2{mg[e], (double)k + d * ((double)O * (1.0 / VP_TWO_PI))};   // true frequency in bins
+                    double d = ph[e] - pv.phPrev[wv * nb + k] - (double)k * invO;
+                    d -= rint(d);                                              // the unwrap: deviation from the nominal advance in [-1/2, 1/2] turns
+                    pv.ana[k] = d2{mg[e], (double)k + d * (double)O};          // true frequency in bins
                 }
                 wave_sync();
                 // bins move to floor(k ratio + 0.5): synthesis bin kk gathers the analysis bins that land on it, in increasing k
@@ -213,13 +261,13 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                 for (int e = 0; e < 9; e++) {
                     if (e == 8 && !lane0) continue;
                     const int kk = kb[e];
-                    const int kc = (int)((double)kk / A.pvRatio);
+                    const int kc = (int)((double)kk * invRatio);
                     double sm = 0.0, sf = 0.0;
                     for (int k = max(kc - 2, 0); k <= min(kc + 2, N); k++) {
                         if ((int)floor((double)k * A.pvRatio + 0.5) == kk) { const d2 v = pv.ana[k]; sm += v.x; sf = v.y * A.pvRatio; }
                     }
                     mg[e] = sm;
-                    pv.inc[wv * nb + kk] = expct * sf;                          // phase advance of the synthesis bin over one hop
+                    pv.inc[wv * nb + kk] = sf * invO;                           // phase advance of the synthesis bin over one hop, in turns
                 }
             }
             __syncthreads();
@@ -232,7 +280,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                     for (int w = 0; w <= wv; w++) sp += pv.inc[w * nb + kk];   // frames of the round in order (frames beyond the stream's last add nothing: they are never live)
                     ph[e] = sp;
                     double sn, cs;
-                    sincos(sp, &sn, &cs);
+                    pv_sincos_turns(sp, sn, cs);
                     const double re = mg[e] * cs, im = mg[e] * sn;
                     if (e == 8) { X.hr = re; X.hi = im; }
                     else if (e & 1) { X.mr[e >> 1] = re; X.mi[e >> 1] = im; }
@@ -248,7 +296,7 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                 for (int e = 0; e < 9; e++) {
                     if (e == 8 && !lane0) continue;
                     pv.phPrev[kb[e]] = pv.phPrev[(wv + 1) * nb + kb[e]];
-                    pv.sum[kb[e]] = ph[e] - VP_TWO_PI * rint(ph[e] * (1.0 / VP_TWO_PI));
+                    pv.sum[kb[e]] = ph[e] - rint(ph[e]);
                 }
             }
         }
