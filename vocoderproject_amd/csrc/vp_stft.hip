@@ -263,8 +263,15 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
                     const int kk = kb[e];
                     const int kc = (int)((double)kk * invRatio);
                     double sm = 0.0, sf = 0.0;
-                    for (int k = max(kc - 2, 0); k <= min(kc + 2, N); k++) {
-                        if ((int)floor((double)k * A.pvRatio + 0.5) == kk) { const d2 v = pv.ana[k]; sm += v.x; sf = v.y * A.pvRatio; }
+                    // (the five candidates are requested at once and chosen from in registers: a conditional read per candidate was a
+                    // dependent LDS round trip each, forty-five per frame -- the stage's largest single cost)
+                    d2 cand[5];
+#pragma unroll
+                    for (int c_ = 0; c_ < 5; c_++) cand[c_] = pv.ana[min(max(kc - 2 + c_, 0), N)];
+#pragma unroll
+                    for (int c_ = 0; c_ < 5; c_++) {
+                        const int k = kc - 2 + c_;
+                        if (k >= 0 && k <= N && (int)floor((double)k * A.pvRatio + 0.5) == kk) { sm += cand[c_].x; sf = cand[c_].y * A.pvRatio; }
                     }
                     mg[e] = sm;
                     pv.inc[wv * nb + kk] = sf * invO;                           // phase advance of the synthesis bin over one hop, in turns
