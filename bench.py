@@ -214,7 +214,7 @@ def parity_vs_oracle(make, S_, N_, fs_, prepare, params, mono_, first_stream, ii
 # fp64 vector instructions one wavefront executes per frame in vp_k_stft_fused<false, false> (its loop body is straight-line: one pass
 # per frame), counted in the disassembly of the built library by tools/kernel_resources.py fp64_op_counts();
 # tests/test_kernel_resources.py fails when the build and these figures part.
-STFT_FP64_OPS_PER_FRAME = {"v_add_f64": 378, "v_mul_f64": 163, "v_fmac_f64": 72}
+STFT_FP64_OPS_PER_FRAME = {"v_mul_f64": 143, "v_add_f64": 338, "v_fma_f64": 40, "v_fmac_f64": 72}      # (round 5: the STFT unit is compiled with -ffp-contract=fast)
 FP64_VECTOR_PEAK_TFLOPS = 78.6                                          # MI355X: 256 CUs x 4 SIMDs x 16 lanes/clk x 2 (FMA) x 2.4 GHz
 
 
@@ -246,7 +246,7 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True, precisio
                              "alg_bytes_per_frame": alg, "alg_bytes_per_launch": alg * frames, "traffic": None}}
     n = STFT_FP64_OPS_PER_FRAME
     insts = sum(n.values())
-    flops = (n["v_add_f64"] + n["v_mul_f64"] + 2 * n["v_fmac_f64"]) * 64
+    flops = (n["v_add_f64"] + n["v_mul_f64"] + 2 * (n["v_fmac_f64"] + n.get("v_fma_f64", 0))) * 64
     out = {"frames_per_s": fps, "kernel": "vp_k_stft_fused<false, false>" if st.fused else "vp_k_stft_frames + vp_k_stft_ola",
            "workload": f"{S} streams x {T} samples, {F}-pt frames hop {hop}, {st.n_frames} frames per stream, one launch per call",
            "us_per_call": dt * 1e6,

@@ -109,8 +109,11 @@ def build(force=False, verbose=False, stamps=False, poison=False):
         # the fused STFT round trip (self-contained).  No SLP vectorisation: left to itself the compiler packs the single-precision kernel's
         # butterflies into v_pk_add_f32 / v_pk_mul_f32 (224 + 68 of them, 230 v_mov to form the pairs, 128 registers and spills), and packed f32
         # is no faster than scalar f32 on this chip (MI355X_MICROARCH.md); the double-precision kernels are unaffected.
+        # -ffp-contract=fast (round 5), for THIS translation unit only: the STFT kernels have no reference arithmetic to reproduce,
+        # so their butterflies, twiddle products and split/merge may fuse multiply-adds -- fewer vector instructions, one rounding less per
+        # pair; the pitch-corrector / vocoder units keep -ffp-contract=off (the numerics contract above).
         # (VP_STFT_EXTRA_FLAGS: experiment builds, tools/ab.sh)
-        jobs.append((os.path.join(CSRC, "vp_stft.hip"), os.path.join(tmp, "stft.o"), os.environ.get("VP_STFT_EXTRA_FLAGS", "-fno-slp-vectorize").split()))
+        jobs.append((os.path.join(CSRC, "vp_stft.hip"), os.path.join(tmp, "stft.o"), os.environ.get("VP_STFT_EXTRA_FLAGS", "-fno-slp-vectorize -ffp-contract=fast").split()))
         jobs.append((os.path.join(CSRC, "vp_capi.hip"), os.path.join(tmp, "capi.o"), []))
 
         def compile_one(job):
