@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 1
+#define VP_ABI_VERSION 2        /* 2 (round 5): + vp_set_wave_specialised, vp_debug_read_ws_stamps; round 4 had added vp_reserve_blocks and the
+                                   vp_stft_* precision / pitch-shift entries and narrowed vp_stft_create to 1024- and 2048-point frames */
 
 /* status codes (the reference has none: it prints to std::cerr and assert(false)s) */
 enum {

@@ -193,7 +193,8 @@ static int pitch_xfft_waves(const vp_handle *h, bool fast, int nBlocks)
 {
     if (!pitch_common(h) || pitch_lite(h, fast) || (nBlocks > 1 && !fast)) return 0;
     int fw = 2 * (h->g.F >> 9);
-    if (const char *e = getenv("VP_XFFT_WAVES")) { const int v = atoi(e); if (v == fw / 2) fw = v; }     // diagnostic: one SEGMENT per wavefront (measured 2 % slower)
+    static const int envWaves = [] { const char *e = getenv("VP_XFFT_WAVES"); return e ? atoi(e) : 0; }();   // (read once: this runs on every process call)
+    if (envWaves == fw / 2) fw = envWaves;                                    // diagnostic: one SEGMENT per wavefront (measured 2 % slower)
     return fw;
 }
 static size_t pitch_xfft_lds(const vp_handle *h) { return vp_pitch_fft_lds_bytes(2 * (h->g.F >> 9)); }                  // (a buffer per TRANSFORM)
@@ -1310,7 +1311,7 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     // front end where the geometry allows it; above 256 streams the register-light builds exist for the FAST recursion only
     // (round 5: where the wave-specialised kernel serves the geometry, a launch of it per block beats the one-launch phase kernel -- 44.8
     // against 53.6 us per block at 256 streams -- and a block loop inside it did not pay: 51.4 us with eight wavefronts, 59.8 with twelve,
-    // the loop level makes everything the programs derive from the geometry and the lane live across all of them; DESIGN.md section 4.16)
+    // the loop level makes everything the programs derive from the geometry and the lane live across all of them; DESIGN.md section 4.3)
     const bool wsBlocks = pitchOnly && !h->timeParallel && pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C);
     if (pitchOnly && n_blocks > 1 && !wsBlocks && (!pitch_lite(h, fast) || fast))
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(64 * NWV) void vp_k_stft_fused(VpStftArgs A)
     if (PV) {
         const int nb = N + 1;
         lds_f64 *p = (lds_f64 *)smem + (stft_lds_base(F, hop) / 8);
+        pv.ana = (lds_d2 *)p + (size_t)wv * nb; p += NWV * nb * 2;           // (the 16-byte type first: the base is 16-byte aligned, nb is odd)
         pv.phPrev = p; p += (NWV + 1) * nb;
-        pv.ana = (lds_d2 *)p + (size_t)wv * nb; p += NWV * nb * 2;
         pv.inc = p; p += NWV * nb;
         pv.sum = p;
     }

@@ -102,12 +102,14 @@ def load_library():
     if hasattr(L, "vp_set_overlap"):
         L.vp_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.vp_get_overlap.argtypes = [C.c_void_p]
-    L.vp_reserve_blocks.argtypes = [C.c_void_p, C.c_int]
-    L.vp_get_reserved_blocks.argtypes = [C.c_void_p]
-    L.vp_debug_alloc_count.argtypes = [C.c_void_p]
-    L.vp_debug_alloc_count.restype = C.c_long
-    L.vp_set_time_parallel.argtypes = [C.c_void_p, C.c_int]
-    L.vp_get_time_parallel.argtypes = [C.c_void_p]
+    if hasattr(L, "vp_reserve_blocks"):                  # (an older A/B library handed over through VP_AMD_LIB still loads)
+        L.vp_reserve_blocks.argtypes = [C.c_void_p, C.c_int]
+        L.vp_get_reserved_blocks.argtypes = [C.c_void_p]
+        L.vp_debug_alloc_count.argtypes = [C.c_void_p]
+        L.vp_debug_alloc_count.restype = C.c_long
+    if hasattr(L, "vp_set_time_parallel"):
+        L.vp_set_time_parallel.argtypes = [C.c_void_p, C.c_int]
+        L.vp_get_time_parallel.argtypes = [C.c_void_p]
     if hasattr(L, "vp_set_wave_specialised"):
         L.vp_set_wave_specialised.argtypes = [C.c_void_p, C.c_int]
         L.vp_get_wave_specialised.argtypes = [C.c_void_p]
