@@ -51,25 +51,42 @@ def main():
     NW = int(os.environ.get("VP_WS_WAVES", "12"))
     print(f"kernel {p.pitch_kernel_name()}  iir={a.iir} yin={a.yin}: microseconds since kernel entry / summed per block, workgroup 0, by block type (nChunk at entry)")
     fast = a.iir == "fast"
+    M = 1 << 64
     for typ in range(4):
         n = int(v[typ * 128 + 0 * 8 + 7])
         if n == 0:
             continue
-        print(f"--- type {typ}: {n} launches, kernel {v[typ * 128 + 5] / n / 100.0:.1f} us")
+        t0 = int(v[typ * 128 + 15 * 8 + 7])                    # the launches' entry clocks, summed
+
+        def ev(w, e):                                          # an EVENT slot: absolute clocks summed -> mean microseconds since entry
+            raw = int(v[typ * 128 + w * 8 + e])
+            return ((raw - t0) % M) / n / 100.0 if raw else 0.0
+
+        def du(w, e):                                          # a DURATION slot
+            return int(v[typ * 128 + w * 8 + e]) / n / 100.0
+
+        print(f"--- type {typ}: {n} launches, kernel {ev(0, 5):.1f} us")
         for w in range(NW):
             if w == 1 and fast:                                # (the windowed-add wavefront has no timers: its slots carry wavefront 0's prologue)
-                print(f"  prologue (wave 0)      requests issued: {v[typ * 128 + 8] / n / 100.0:.1f} | consumed: {v[typ * 128 + 9] / n / 100.0:.1f} | barrier passed: {v[typ * 128 + 10] / n / 100.0:.1f}")
+                print(f"  prologue (wave 0)      requests issued: {ev(1, 0):.1f} | consumed: {ev(1, 1):.1f} | barrier passed: {ev(1, 2):.1f}")
                 continue
             names = REC if w < 2 else PROD if w < NW - 4 else (BG0, BG1, BG2, LEAD)[w - (NW - 4)]
             role = "recursion" if names is REC else "producer" if names is PROD else "background" + (" (lead)" if w == NW - 1 else "")
+            events = {0, 6, 7} if names is REC else {0, 7} if names is PROD else set(range(8))
             cells = []
             for e in range(8):
                 if w == 0 and e in (5, 7):
                     continue
-                val = v[typ * 128 + w * 8 + e] / n / 100.0
+                val = ev(w, e) if e in events else du(w, e)
                 if val or e == 0:
                     cells.append(f"{names.get(e, str(e))}: {val:.1f}")
             print(f"  wave {w} {role:18s} " + " | ".join(cells))
+        fine = ["loop entry", "state rolled", "notes requested", "analysis marks", "coefficients adopted", "zeroing seen"]
+        print("  lead, first start in detail   " + " | ".join(f"{nm}: {ev(12, k):.1f}" for k, nm in enumerate(fine)))
+        finep = ["published seen", "adopted (0) / -", "grain table (0) / quotient table (1)", "barrier", "first chunk gathered", "barrier", "rest gathered"]
+        for r in (0, 1):
+            print(f"  producer {r}, first Start's segment   " + " | ".join(f"{nm}: {ev(13 + r, k):.1f}" for k, nm in enumerate(finep)))
+        print("  recursion, instance taken up at   " + " | ".join(f"{ev(15, k):.1f}" for k in range(7) if v[typ * 128 + 15 * 8 + k]))
 
 
 if __name__ == "__main__":

@@ -181,6 +181,8 @@ struct WsCtl {                          // ints in LDS, zeroed by thread 0 in th
     int instMode[WS_MAXI];              // per instance, decided by the producers: 0 nothing, 1 output only, 2 recursion + output
     int ishareBG[4], ishareP[4];
     int fftFlag[4];
+    int gNext[WS_MAXS + 1];             // per segment: the gather pass's next trip (taken by whichever wavefront comes for one)
+    int gDone[WS_MAXI];                 // per instance: finished trips among those that start in its chunk's stretch of outEFrame
 };
 
 // The block's SCHEDULE (PitchProcess.cpp:171-189): per chunk step [Cont of the running frame], then, when a frame starts there,
