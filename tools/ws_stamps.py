@@ -52,6 +52,8 @@ def main():
     print(f"kernel {p.pitch_kernel_name()}  iir={a.iir} yin={a.yin}: microseconds since kernel entry / summed per block, workgroup 0, by block type (nChunk at entry)")
     fast = a.iir == "fast"
     M = 1 << 64
+    if v[0]:
+        print(f"gather (workgroup 0, all launches): {int(v[0])} trips, {v[1] / max(int(v[0]), 1) / 100.0:.2f} us each; {int(v[2])} grain pairs, {int(v[3])} by the general form")
     for typ in range(4):
         n = int(v[typ * 128 + 0 * 8 + 7])
         if n == 0:

@@ -183,6 +183,7 @@ struct WsCtl {                          // ints in LDS, zeroed by thread 0 in th
     int fftFlag[4];
     int gNext[WS_MAXS + 1];             // per segment: the gather pass's next trip (taken by whichever wavefront comes for one)
     int gDone[WS_MAXI];                 // per instance: finished trips among those that start in its chunk's stretch of outEFrame
+    int gNT[WS_MAXS + 1], gLo[WS_MAXS + 1], gHi[WS_MAXS + 1], gNg[WS_MAXS + 1];   // per segment, from its grain table: trips, first sample, end, grains
 };
 
 // The block's SCHEDULE (PitchProcess.cpp:171-189): per chunk step [Cont of the running frame], then, when a frame starts there,
