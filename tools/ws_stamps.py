@@ -79,6 +79,8 @@ def main():
             for e in range(8):
                 if w == 0 and e in (5, 7):
                     continue
+                if w == 1 and not fast and e in (0, 1, 2):     # (EXACT: the second recursion wavefront's slots 0-2 also take wavefront 0's prologue stamps)
+                    continue
                 val = ev(w, e) if e in events else du(w, e)
                 if val or e == 0:
                     cells.append(f"{names.get(e, str(e))}: {val:.1f}")
