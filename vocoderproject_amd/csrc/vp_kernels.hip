@@ -221,7 +221,20 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
     float *sr1 = sr0 + g.inSize;
     const int mono = c.inMono;
     const float *xin = in + (size_t)s * (mono ? 1 : 3) * g.N;
-    if (!mono) {
+    // Four samples per lane and request where everything is a multiple of four (round 5: these loops are bound by the NUMBER of memory
+    // instructions, and the ring position by a run-time modulo is forty vector instructions per sample)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int base = (c.inCounter + boff) % g.inSize;                        // (uniform: one modulo per launch)
+    const bool vec = ((g.N | g.inSize | base) & 3) == 0 && (((size_t)xin | (size_t)vr | (size_t)sr0) & 15) == 0;
+    if (vec) {
+        for (int i = 4 * tid; i < g.N; i += 4 * nt) {
+            int p = base + i;
+            p -= (p >= g.inSize) ? g.inSize : 0;                              // (N <= inSize: one wrap at most, never inside the four)
+            *(f4v *)(vr + p) = *(const f4v *)(xin + i);
+            if (!mono) { *(f4v *)(sr0 + p) = *(const f4v *)(xin + g.N + i); *(f4v *)(sr1 + p) = *(const f4v *)(xin + 2 * g.N + i); }
+            else if (mono == 1) { *(f4v *)(sr0 + p) = f4v{0.f, 0.f, 0.f, 0.f}; *(f4v *)(sr1 + p) = f4v{0.f, 0.f, 0.f, 0.f}; }
+        }
+    } else if (!mono) {
         for (int i = tid; i < g.N; i += nt) {
             int p = (c.inCounter + boff + i) % g.inSize;
             vr[p] = xin[i];
@@ -240,7 +253,18 @@ __device__ __forceinline__ void ingest_gate_block(const VpGeom &g, const VpCall 
     // the side chain's gate is only consulted by the vocoder (VocoderProcess.cpp:199-204); an all-zero ring sums to 0
     const bool needS = c.vocOn && mono != 2;
     double sv = 0.0, ss = 0.0;
-    if (needS) {
+    if (vec) {
+        // (the sums' order differs from the one-sample loops': any order is inside the rounding band the verdict below allows for)
+        for (int i = 4 * tid; i < g.inSize; i += 4 * nt) {
+            const f4v a = *(const f4v *)(vr + i);
+            { const double a0 = (double)a.x, a1 = (double)a.y, a2 = (double)a.z, a3 = (double)a.w; sv += a0 * a0; sv += a1 * a1; sv += a2 * a2; sv += a3 * a3; }
+            if (needS) {
+                const f4v b = *(const f4v *)(sr0 + i);
+                const double b0 = (double)b.x, b1 = (double)b.y, b2 = (double)b.z, b3 = (double)b.w;
+                ss += b0 * b0; ss += b1 * b1; ss += b2 * b2; ss += b3 * b3;
+            }
+        }
+    } else if (needS) {
         for (int i = tid; i < g.inSize; i += nt) {
             double a = (double)vr[i], b = (double)sr0[i];
             sv += a * a;
