@@ -134,14 +134,18 @@ static bool pitch_lite(const vp_handle *h, bool iirFast)
     return h->g.S > 256 && (iirFast || h->g.orderPitch <= 16) && h->pitchLds <= 80 * 1024 && h->g.htabGlobal;
 }
 
-// geometry and order for which the common-case builds (vp_k_pitch*_c) are valid
-static bool pitch_common(const vp_handle *h)
+// geometry and order for which the common-case builds (vp_k_pitch*_c) are valid: the geometric predicate proper -- all the register-light
+// common-case builds need, they carry the eight-lag form of the certified YIN --
+static bool pitch_common_geom(const vp_handle *h)
 {
     // (the last term: room behind the YIN window's prefix sums in eFrame for the quarter sums of xcorr8_quarter, vp_pitch.inc xc8_ok)
-    // (round 4: frames of one or two whole 512-sample segments -- 22.05 and 44.1 kHz with the plugin's geometry -- and room for the FFT
-    // cross-correlation's tables and exchange buffers: the full-register common-case builds carry no other form of the certified YIN)
-    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512 && h->g.eLen >= h->g.F + 4 * h->g.tauMax + 1 &&
-           (h->g.F == 512 || h->g.F == 1024) && h->pitchLds + 16 + vp_pitch_fft_lds_bytes(2 * (h->g.F >> 9)) <= h->ldsMax;
+    return (h->g.C & 63) == 0 && h->g.orderPitch <= 15 && h->g.tauMax <= 512 && h->g.eLen >= h->g.F + 4 * h->g.tauMax + 1;
+}
+// ... and, for the full-register ones (round 4): frames of one or two whole 512-sample segments -- 22.05 and 44.1 kHz with the plugin's
+// geometry -- and room for the FFT cross-correlation's tables and exchange buffers: they carry no other form of the certified YIN
+static bool pitch_common(const vp_handle *h)
+{
+    return pitch_common_geom(h) && (h->g.F == 512 || h->g.F == 1024) && h->pitchLds + 16 + vp_pitch_fft_lds_bytes(2 * (h->g.F >> 9)) <= h->ldsMax;
 }
 
 // geometry and modes for which the analysis front end of multi-block launches (vp_k_pitch_front) can stand in for the serial kernel's
@@ -159,7 +163,7 @@ struct PitchPlan { vp_dsp_kernel fn; const char *name; size_t lds; };
 #define VP_PLAN(K, LDS) PitchPlan{K, #K, LDS}
 static PitchPlan pitch_plan(const vp_handle *h, bool fast, int nBlocks)
 {
-    const bool lite = pitch_lite(h, fast), com = pitch_common(h);
+    const bool lite = pitch_lite(h, fast), com = lite ? pitch_common_geom(h) : pitch_common(h);
     const size_t lds = h->pitchLds;
     if (nBlocks > 1) {                                    // (`lite` multi-block launches exist for the FAST recursion only: process_blocks_device)
         if (lite) return com ? VP_PLAN(vp_k_pitch_lite_fast_multi_c, lds) : VP_PLAN(vp_k_pitch_lite_fast_multi, lds);
