@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VP_ABI_VERSION 2        /* 2 (round 5): + vp_set_wave_specialised, vp_debug_read_ws_stamps; round 4 had added vp_reserve_blocks and the
+#define VP_ABI_VERSION 3        /* 3 (round 6): + VP_ERR_TIMEOUT, vp_debug_set_spin_limit (additions only: a version-2 caller keeps working); 2 (round 5): + vp_set_wave_specialised, vp_debug_read_ws_stamps; round 4 had added vp_reserve_blocks and the
                                    vp_stft_* precision / pitch-shift entries and narrowed vp_stft_create to 1024- and 2048-point frames */
 
 /* status codes (the reference has none: it prints to std::cerr and assert(false)s) */
@@ -37,7 +37,13 @@ enum {
     VP_ERR_ORDER = -5,           /* LPC order above its parameter maximum (VocoderProcess.cpp:145-148,161-164) */
     VP_ERR_NO_DEVICE = -6,       /* no usable HIP device: this library has NO CPU fallback */
     VP_ERR_HIP = -7,             /* a HIP runtime call failed; see vp_last_error() */
-    VP_ERR_OOM = -8
+    VP_ERR_OOM = -8,
+    VP_ERR_TIMEOUT = -9          /* a kernel's bounded inter-wavefront wait ran out (a lost signal, or a wavefront held up for about a second
+                                    by a debugger / preemption): that launch's output and the handle's device state are INVALID.  The handle
+                                    is poisoned -- every later process call returns this code -- until it is prepared again.  Reported by the
+                                    call that synchronises behind the launch (vp_process_block*, vp_process_blocks with host pointers,
+                                    vp_synchronize) or, on the device-pointer entry points, by the next call on the handle; the reference's
+                                    counterpart is the assert(false) on impossible state, PitchProcess.cpp:824,828 */
 };
 
 /* The ten plugin parameters, same ids, ranges and defaults as
@@ -243,8 +249,12 @@ int vp_get_num_streams(const vp_handle *h);
 /* Copies one stream's pitch-tracker state to the host (synchronises). */
 int vp_read_pitch_state(vp_handle *h, int stream, vp_pitch_state *out);
 
-/* hipDeviceSynchronize on the handle's device. */
+/* hipDeviceSynchronize on the handle's device, then the verdict on everything launched so far: VP_OK, or the code that poisoned the
+ * handle (VP_ERR_TIMEOUT / VP_ERR_HIP).  A host that drives the device-pointer entry points calls this before it trusts their output. */
 int vp_synchronize(vp_handle *h);
+/* Diagnostic: polls a kernel's bounded inter-wavefront wait makes before it gives up (default 2^22, about a second).  The test
+ * suite sets 1 to force the timeout path (tests/test_gpu_round6.py). */
+int vp_debug_set_spin_limit(vp_handle *h, int polls);
 
 /* Kernel timing with HIP events on the launch stream (bench.py's roofline figures).
  * vp_profile_enable(h, k) brackets the kernel launches of every k-th process call with events (k = 1: every call;
@@ -271,7 +281,7 @@ int vp_read_ub_counters(vp_handle *h, long out[5]);
 
 /* Slots 0..58: diagnostic build (-DVP_STAMPS) only, per-phase timers (100 MHz ticks) of workgroup 0, all zero in
  * the product build.  Slots 59 / 60 / 61 (every build): wavefronts whose bounded wait for an in-workgroup flag (YIN prefix
- * sums / LPC coefficients / grain table) ran out -- always 0; anything else is a bug.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
+ * sums / LPC coefficients / grain table) ran out -- always 0; anything else has also raised VP_ERR_TIMEOUT and poisoned the handle.  Slots 62 / 63 (every build): frames, over all streams, whose pitch decision VP_YIN_XCORR
  * certified / handed to the reference's arithmetic. */
 int vp_debug_read_stamps(vp_handle *h, unsigned long long out[64], int reset);
 /* Diagnostic build only: per-wavefront timers of the wave-specialised pitch kernel, [4 block types][16 wavefronts][8 slots] (tools/ws_stamps.py). */

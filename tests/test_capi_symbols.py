@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.vp_abi_version() == 2
+    assert lib.vp_abi_version() == 3
     lib.vp_error_string.restype = C.c_char_p
     assert lib.vp_error_string(0) == b"ok"
     assert lib.vp_error_string(-3) == b"Invalid overlap"          # VocoderProcess.cpp:112

@@ -1,0 +1,277 @@
+"""GPU tests added in round 6 (through the C ABI).
+
+* a bounded inter-wavefront wait that runs out is an ERROR: VP_ERR_TIMEOUT from the call that synchronises behind the launch, the
+  handle poisoned until it is prepared again (round-5 verdict, weak item 2; the reference asserts on impossible state,
+  PitchProcess.cpp:824,828);
+* the exact mode's two recursion wavefronts on blocks of 2 cpf - 1 chunk steps and more (the circular wait the round-5 advisor
+  described: prepareExplicit(44100, 1028 .. 1160, F = 1024, H = 512));
+* vp_set_wave_specialised / vp_set_time_parallel toggled in the middle of a run on ONE handle (the frame in flight crosses from
+  one kernel family to the other through HBM), in both arithmetic modes, entry states nChunk0 != 0 included.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FS = 44100.0
+VP_ERR_TIMEOUT = -9
+
+
+def _streams(S, T, **kw):
+    from vocoderproject_amd.synth import make_streams
+    return np.ascontiguousarray(make_streams(S, T, **kw).numpy())
+
+
+def _edge_streams(T, fs=FS):
+    from test_gpu_round5 import _edge_streams as e
+    return e(T, fs)
+
+
+def _assert_equal(got, ref, what=""):
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"{what}: {len(bad)} samples differ, first at {bad[0]}, max abs {np.abs(got - ref).max()}"
+
+
+def _state_key(p, s):
+    d = p.pitch_state(s)
+    d["a"] = d["a"].tobytes()
+    return sorted(d.items())
+
+
+def _timeouts(p):
+    v = p.debug_stamps(reset=False)
+    return [round(v[i] * 100.0) for i in (59, 60, 61)]
+
+
+# ---- timeouts are errors -----------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("iir", ["fast", "exact"])
+@pytest.mark.parametrize("ws", [True, False])
+def test_forced_wait_timeout_is_an_error_and_poisons_the_handle(ws, iir):
+    """With the bounded waits cut to ONE poll the kernels' inter-wavefront waits run out (the wave-specialised kernel has dozens per
+    block; the phase kernels wait for the prefix sums / the FFT's partial spectra / the grain table built ahead).  The host-pointer call
+    synchronises behind its launch and must return VP_ERR_TIMEOUT, every later call must too, vp_last_error must say why, and a new
+    prepare must give a working handle whose output equals the oracle's."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    N, S = 1024, 6
+    x = _streams(S, N * 8)
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode(iir)
+    p.set_yin_mode("xcorr")
+    p.set_wave_specialised(ws)
+    assert p.pitch_kernel_name().startswith("vp_k_pitch_ws") == ws
+    p.debug_set_spin_limit(1)
+    codes = []
+    for b in range(6):                                       # (the first frames of a run need no waits that can lose: keep going)
+        try:
+            p.process(np.ascontiguousarray(x[:, :, b * N:(b + 1) * N]))
+            codes.append(0)
+        except VpError as e:
+            codes.append(e.code)
+            assert "wait" in str(e) or "timed out" in str(e), str(e)
+    assert VP_ERR_TIMEOUT in codes, codes
+    first = codes.index(VP_ERR_TIMEOUT)
+    assert all(c == VP_ERR_TIMEOUT for c in codes[first:]), codes           # poisoned: every later call reports it
+    with pytest.raises(VpError) as ei:
+        p.synchronize()
+    assert ei.value.code == VP_ERR_TIMEOUT
+    assert sum(_timeouts(p)) > 0                                            # (the debug counters agree)
+    # the device-pointer entry points report it too (on the call after the launch)
+    import torch
+    d_in = torch.zeros((S, 3, N), dtype=torch.float32, device="cuda")
+    d_out = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
+    with pytest.raises(VpError) as ei:
+        p.process_device(d_in, d_out)
+    assert ei.value.code == VP_ERR_TIMEOUT
+    # prepare again: a clean handle
+    p.debug_set_spin_limit(1 << 22)
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode("exact")
+    got = p.run(x)
+    assert _timeouts(p)[2] >= 0
+    for s in (0, S - 1):
+        o = O.OracleStream(vocBool=0)
+        o.prepare_to_play(FS, N)
+        _assert_equal(got[s], o.run(x[s]), f"after re-prepare, stream {s}")
+    p.close()
+
+
+def test_timeout_on_device_entry_point_is_reported_by_the_next_call():
+    """vp_process_block_device does not synchronise: the launch that timed out returns VP_OK, vp_synchronize (or the next process
+    call) returns VP_ERR_TIMEOUT."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    N, S = 1024, 4
+    x = torch.from_numpy(_streams(S, N * 6)).cuda()
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode("fast")
+    p.set_yin_mode("xcorr")
+    p.debug_set_spin_limit(1)
+    d_out = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
+    raised = None
+    for b in range(6):
+        try:
+            p.process_device(x[:, :, b * N:(b + 1) * N].contiguous(), d_out)
+        except VpError as e:
+            raised = e.code
+            break
+    if raised is None:
+        with pytest.raises(VpError) as ei:
+            p.synchronize()
+        raised = ei.value.code
+    assert raised == VP_ERR_TIMEOUT
+    p.close()
+
+
+# ---- EXACT mode, blocks of 2 cpf - 1 steps and more ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N", [1028, 1100, 1160])
+def test_exact_mode_two_chunks_per_frame_three_steps_per_block(N):
+    """F = 1024, H = 512 (two chunks per frame), host blocks just above 1024 samples: every block runs three chunk steps = 2 cpf - 1,
+    i.e. both recursion wavefronts of the exact mode hold chunks of different frames whose additions wait for each other's turn while
+    the next Start waits for the older frame's last addition (the round-5 advisor's circular wait).  Bit-exact against the oracle and
+    the phase kernels; no wait runs out."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    F, H, W, h = 1024, 512, 512, 128
+    x = _edge_streams(N * 24)
+    S = x.shape[0]
+    outs = {}
+    for ws in (True, False):
+        p = BatchVocoderProcessor(vocBool=0)
+        p.prepareExplicit(FS, N, S, F, H, W, h)
+        p.set_iir_mode("exact")
+        p.set_yin_mode("xcorr")
+        p.set_wave_specialised(ws)
+        if ws and not p.pitch_kernel_name().startswith("vp_k_pitch_ws"):
+            p.close()
+            pytest.skip(f"N={N}: the block's voice window does not fit the wave-specialised kernel's carve")
+        outs[ws] = (p.run(x), [_state_key(p, s) for s in range(S)], p.ub_counters())
+        assert _timeouts(p) == [0, 0, 0]
+        p.close()
+    _assert_equal(outs[True][0], outs[False][0], f"N={N}: wave-specialised vs phase kernels")
+    assert outs[True][1:] == outs[False][1:]
+    for s in range(S):
+        o = O.OracleStream(vocBool=0)
+        o.prepare_explicit(FS, N, F, H, W, h)
+        _assert_equal(outs[True][0][s], o.run(x[s]), f"N={N} stream {s} vs oracle")
+
+
+# ---- kernel families switched mid-run on one handle ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("iir", ["exact", "fast"])
+@pytest.mark.parametrize("N,every", [(1024, 1), (1024, 3), (512, 2), (256, 5)])
+def test_wave_specialised_toggled_mid_run_on_one_handle(N, every, iir):
+    """include/vp_amd.h promises the same bits from vp_k_pitch_ws* and the phase kernels and allows vp_set_wave_specialised at any
+    time: the frame in flight (eFrame, outEFrame / yFrame ranges, impulse response, tracker state) then crosses from one family to the
+    other through HBM.  Toggle every `every` blocks -- entry states nChunk0 = 1, 2, 3 all occur -- and compare with an untoggled run
+    (bit for bit, both modes) and, in the exact mode, with the oracle."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    B = 36 if N >= 512 else 96
+    x = _edge_streams(N * B)
+    S = x.shape[0]
+
+    def run(toggle):
+        p = BatchVocoderProcessor(vocBool=0)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode(iir)
+        p.set_yin_mode("xcorr")
+        out = np.empty((S, 2, N * B), np.float32)
+        names = set()
+        on = True
+        for b in range(B):
+            if toggle and b % every == 0:
+                on = not on
+                p.set_wave_specialised(on)
+            names.add(p.pitch_kernel_name())
+            out[:, :, b * N:(b + 1) * N] = p.process(np.ascontiguousarray(x[:, :, b * N:(b + 1) * N]))
+        res = (out, [_state_key(p, s) for s in range(S)], p.ub_counters())
+        assert _timeouts(p) == [0, 0, 0]
+        p.close()
+        return res, names
+
+    (a, na), (b_, nb) = run(True), run(False)
+    assert len(na) == 2 and len(nb) == 1, (na, nb)                          # both families really ran in the toggled run
+    _assert_equal(a[0], b_[0], f"N={N} every={every} {iir}: toggled vs untoggled")
+    assert a[1:] == b_[1:]
+    if iir == "exact":
+        for s in range(S):
+            o = O.OracleStream(vocBool=0)
+            o.prepare_to_play(FS, N)
+            _assert_equal(a[0][s], o.run(x[s]), f"stream {s} vs oracle")
+
+
+@pytest.mark.parametrize("iir", ["exact", "fast"])
+def test_single_block_and_multi_block_calls_mixed_with_kernel_switches(iir):
+    """One handle, device-pointer calls: single blocks on the wave-specialised kernel, a four-block call with vp_set_time_parallel
+    (the one-launch phase kernel behind the analysis front end), single blocks with the wave-specialised kernel switched off, a
+    three-block call without the front end ... The output must equal a plain block-by-block run bit for bit."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    N, S = 1024, 9
+    plan = [("one", True, False), ("multi", 4, True), ("one", False, False), ("one", True, False), ("multi", 3, False),
+            ("one", True, False), ("multi", 2, True), ("one", False, False), ("one", True, False)]
+    B = sum(k[1] if k[0] == "multi" else 1 for k in plan)
+    x = _edge_streams(N * B)
+    ref_p = BatchVocoderProcessor(vocBool=0)
+    ref_p.prepareToPlay(FS, N, S)
+    ref_p.set_iir_mode(iir)
+    ref_p.set_yin_mode("xcorr")
+    ref = ref_p.run(x)
+    ref_state = [_state_key(ref_p, s) for s in range(S)]
+    ref_p.close()
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode(iir)
+    p.set_yin_mode("xcorr")
+    p.reserve_blocks(4)
+    xd = torch.from_numpy(x).cuda()
+    out = np.empty_like(ref)
+    b = 0
+    for kind, arg, tp in plan:
+        if kind == "one":
+            p.set_wave_specialised(arg)
+            p.set_time_parallel(False)
+            d_out = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
+            p.process_device(xd[:, :, b * N:(b + 1) * N].contiguous(), d_out)
+            out[:, :, b * N:(b + 1) * N] = d_out.cpu().numpy()
+            b += 1
+        else:
+            p.set_wave_specialised(True)
+            p.set_time_parallel(tp)
+            d_in = torch.stack([xd[:, :, (b + k) * N:(b + k + 1) * N] for k in range(arg)]).contiguous()
+            d_out = torch.empty((arg, S, 2, N), dtype=torch.float32, device="cuda")
+            p.process_blocks_device(d_in, d_out)
+            o = d_out.cpu().numpy()
+            for k in range(arg):
+                out[:, :, (b + k) * N:(b + k + 1) * N] = o[k]
+            b += arg
+    p.synchronize()
+    _assert_equal(out, ref, f"{iir}: mixed calls vs block by block")
+    assert [_state_key(p, s) for s in range(S)] == ref_state
+    assert _timeouts(p) == [0, 0, 0]
+    p.close()
+
+
+def test_stft_plain_roundtrip_does_not_depend_on_the_phase_vocoder_attribute():
+    """vp_stft_create validates its arguments before it touches the device, and a plain handle works whatever happened to the
+    phase-vocoder build's LDS attribute (round-5 advisor): bad arguments -> VP_ERR_INVALID_ARG / VP_ERR_GEOMETRY without a sticky HIP error."""
+    import ctypes as C
+    import torch
+    from vocoderproject_amd import load_library
+    from vocoderproject_amd.processor import StftRoundTrip
+    L = load_library()
+    h = C.c_void_p()
+    assert L.vp_stft_create(0, 0, 4096, 1024, 256, C.byref(h)) == -1
+    assert L.vp_stft_create(0, 2, 4096, 1000, 250, C.byref(h)) == -4
+    st = StftRoundTrip(2, 8192)
+    x = torch.randn(2, 8192, device="cuda")
+    y = torch.empty_like(x)
+    st(x, y)
+    torch.cuda.synchronize()
+    assert float((x[:, 1024:-1024] - y[:, 1024:-1024]).abs().max()) < 1e-5
+    st.close()

@@ -13,6 +13,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -55,15 +56,26 @@ LIB_STAMPS = os.path.join(HERE, "libvp_amd_stamps.so")
 LIB_POISON = os.path.join(HERE, "libvp_amd_poison.so")
 
 
-CACHE_CAP_BYTES = 200 << 20
+CACHE_CAP_BYTES = 600 << 20      # (one full set of product, stamps, poison and side-build objects is ~200 MB: room for three generations)
 
 
 def prune_cache(cap=CACHE_CAP_BYTES):
     """Least-recently-used objects go until the object cache is below `cap` (it once grew to 1.2 GB of experiment objects)."""
     cache = os.path.join(HERE, ".build_cache")
     try:
-        ents = [(os.path.getmtime(os.path.join(cache, f)), os.path.getsize(os.path.join(cache, f)), os.path.join(cache, f))
-                for f in os.listdir(cache)]
+        ents = []
+        now = time.time()
+        for f in os.listdir(cache):
+            p = os.path.join(cache, f)
+            try:
+                if ".part" in f:
+                    # a half-written object of a build that is gone (a live one is minutes old at most): not part of the cache
+                    if now - os.path.getmtime(p) > 3600:
+                        os.remove(p)
+                    continue
+                ents.append((os.path.getmtime(p), os.path.getsize(p), p))
+            except OSError:
+                pass                                               # (another build pruned or replaced it meanwhile)
     except OSError:
         return
     total = sum(e[1] for e in ents)
@@ -135,9 +147,12 @@ def build(force=False, verbose=False, stamps=False, poison=False):
             cached = os.path.join(cache, os.path.basename(obj) + "." + hsh.hexdigest()[:20])
             # force=True (what __graft_entry__.build() passes) COMPILES: the cache only serves the development loop
             if os.path.exists(cached) and not force and not os.environ.get("VP_NO_OBJ_CACHE"):
-                shutil.copy(cached, obj)
-                os.utime(cached)                                   # (LRU: served objects are the young ones)
-                return obj
+                try:
+                    shutil.copy(cached, obj)
+                    os.utime(cached)                               # (LRU: served objects are the young ones)
+                    return obj
+                except OSError:
+                    pass                                           # (a concurrent build's prune_cache() took it between the test and the copy: compile)
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

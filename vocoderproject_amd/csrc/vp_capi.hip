@@ -43,6 +43,11 @@ struct vp_handle {
     int *dMapAll = nullptr;                     // [S] device storage of the cohorts' maps, back to back
     std::vector<int> mapHost;                   // staging for its upload
     bool poisoned = false;                      // a HIP call failed inside a process call: host counters and device state may disagree
+    int poisonCode = VP_ERR_HIP;                // ... or (VP_ERR_TIMEOUT) a kernel's bounded inter-wavefront wait ran out: its output is void
+    // the fault word: pinned host memory the kernels can write (VpDev::fault).  Looked at -- a plain host read, no synchronisation --
+    // at the top of every process call and behind every synchronisation this library makes itself (check_fault).
+    unsigned int *faultHost = nullptr, *faultDev = nullptr;
+    int spinLimit = 1 << 22;                    // VpDev::spinLimit (vp_debug_set_spin_limit)
     // the batched lane-per-window vocoder pipeline (vp_voc2.hip): scratch, the orders it must cover, and who picks it
     VpV2 v2;
     int vocPath = VP_VOC_AUTO, oVmax = 0, oSmax = 0, nWinMax = 0;
@@ -98,6 +103,29 @@ static int fail_hip(vp_handle *h, hipError_t e, const char *what)
 }
 #define HIPCHK(h, call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail_hip((h), _e, #call); } while (0)
 
+// A poisoned handle answers every process call with the code that poisoned it until it is prepared again.
+static int poisoned_rc(vp_handle *h)
+{
+    h->lastError = h->poisonCode == VP_ERR_TIMEOUT
+        ? "an earlier launch timed out on an inter-wavefront wait (its output and the device state are void): prepare again"
+        : "an earlier HIP failure left the handle out of step with its device state: prepare again";
+    return h->poisonCode;
+}
+// The kernels' fault word (vp_timeout, vp_kernels.hip).  A plain read of pinned host memory: what it shows is whatever launches have
+// COMPLETED so far, so a timeout is reported by the call that synchronises behind the launch (the host-pointer entry points,
+// vp_synchronize, the vp_read_* calls) or, for the device-pointer entry points, by the next call on the handle.
+static int check_fault(vp_handle *h)
+{
+    if (!h->faultHost) return VP_OK;
+    const unsigned f = *(volatile unsigned int *)h->faultHost;
+    if (f == 0) return VP_OK;
+    h->poisoned = true; h->poisonCode = VP_ERR_TIMEOUT;
+    char buf[200];
+    snprintf(buf, sizeof buf, "a kernel's bounded wait ran out (counter dbg[%u], see vp_debug_read_stamps): the block's output is invalid; prepare again", f & 0xff);
+    h->lastError = buf;
+    return VP_ERR_TIMEOUT;
+}
+
 // every device allocation of a handle goes through here: prepare and vp_reserve_blocks allocate, vp_process_*() never do
 // (include/vp_amd.h; tests/test_gpu_round4.py watches the count across every process entry point)
 static hipError_t vp_malloc(vp_handle *h, void **q, size_t bytes)
@@ -120,6 +148,7 @@ extern "C" const char *vp_error_string(int code)
     case VP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case VP_ERR_HIP: return "HIP runtime error";
     case VP_ERR_OOM: return "out of device memory";
+    case VP_ERR_TIMEOUT: return "a kernel's bounded inter-wavefront wait ran out: the output is invalid, prepare again";
     default: return "unknown error";
     }
 }
@@ -337,6 +366,16 @@ extern "C" int vp_create(int device, vp_handle **out)
         delete h;
         return VP_ERR_NO_DEVICE;
     }
+    void *fh = nullptr, *fd = nullptr;
+    if (hipHostMalloc(&fh, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&fd, fh, 0) != hipSuccess) {
+        if (fh) (void)hipHostFree(fh);
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(h->ownStream); (void)hipStreamDestroy(h->auxStream); (void)hipEventDestroy(h->evFork); (void)hipEventDestroy(h->evJoin);
+        delete h;
+        return VP_ERR_OOM;
+    }
+    memset(fh, 0, 64);
+    h->faultHost = (unsigned int *)fh; h->faultDev = (unsigned int *)fd;
     *out = h;
     return VP_OK;
 }
@@ -368,6 +407,7 @@ extern "C" int vp_destroy(vp_handle *h)
     if (h->auxStream) (void)hipStreamDestroy(h->auxStream);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->faultHost) (void)hipHostFree(h->faultHost);
     delete h;
     return VP_OK;
 }
@@ -742,6 +782,8 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
             return VP_ERR_HIP;
         }
     }
+    d.fault = h->faultDev; d.spinLimit = h->spinLimit;
+    *(volatile unsigned int *)h->faultHost = 0;                              // (the device is idle: prepare synchronised it)
     h->g = g;
     h->d = d;
     h->inCounter = g.toKeep + g.latency;                                     // MyBuffer.cpp:60-62
@@ -749,7 +791,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     h->currCounter = g.toKeep;
     // VocoderProcess.cpp:39, PitchProcess.cpp:85,90: startSample = 0, nChunk = 0 for every instance
     h->cohorts.assign(1, vp_handle::Cohort{h->params.pitchBool, h->params.vocBool, 0, 0, 0, S, nullptr, {}});
-    h->cohortsDirty = false; h->poisoned = false;
+    h->cohortsDirty = false; h->poisoned = false; h->poisonCode = VP_ERR_HIP;
     h->sparams.assign((size_t)S, h->params);                                 // prepare starts every stream from the handle's set
     h->spHost.assign((size_t)S, VpStreamParams{});
     h->synthNonZero = 0;                                                     // the rings start zeroed
@@ -874,7 +916,8 @@ static int sync_stream_state(vp_handle *h, hipStream_t st)
 static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStream_t st, int inplace, int nBlocks = 1, bool mono = false)
 {
     const VpGeom &g = h->g;
-    if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
+    if (h->poisoned) return poisoned_rc(h);
+    if (int frc = check_fault(h)) return frc;                                 // (an earlier launch of this handle timed out)
     const vp_params P = h->params;                                           // snapshot at call entry
     h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;   // all kernels of every k-th call
     if (P.lpcVoice > VP_ORDER_MAX || P.lpcSynth > VP_ORDER_MAX_SYNTH) return VP_ERR_ORDER;
@@ -1152,7 +1195,8 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     // the grid is continuous: window k starts at vStart[0] + k h (in block-0 coordinates)
     for (int b = 1; b < nb; b++)
         if (mb.nWin[b] > 0 && b * g.N + mb.vStart[b] != mb.vStart[0] + mb.first[b] * g.h) return VP_OK;
-    if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
+    if (h->poisoned) return poisoned_rc(h);
+    if (int frc = check_fault(h)) return frc;
     if (NWs > h->v2mbWin) return VP_OK;                                      // beyond what vp_reserve_blocks sized: no allocation here
     h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
     VpCall c;
@@ -1234,7 +1278,8 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     if (NWs < 1 || mb.nWin[0] < 1) return VP_OK;
     for (int b = 1; b < nb; b++)
         if (mb.nWin[b] > 0 && b * g.N + mb.vStart[b] != mb.vStart[0] + mb.first[b] * g.h) return VP_OK;
-    if (h->poisoned) { h->lastError = "an earlier HIP failure left the handle out of step with its device state: prepare again"; return VP_ERR_HIP; }
+    if (h->poisoned) return poisoned_rc(h);
+    if (int frc = check_fault(h)) return frc;
     if (NWs > h->v2mbWin || !h->pLin) return VP_OK;                          // not reserved (vp_reserve_blocks): block by block, no allocation here
     h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
     struct Poison { vp_handle *h; bool armed; ~Poison() { if (armed) h->poisoned = true; } } guard{h, true};
@@ -1375,7 +1420,7 @@ extern "C" int vp_process_block_mono(vp_handle *h, const float *voice, float *ou
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(out, h->stageOut, nOut * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
     HIPCHK(h, hipStreamSynchronize(h->ownStream));
-    return VP_OK;
+    return check_fault(h);                                                    // (behind the synchronisation: this call's own launches included)
 }
 
 // Host-pointer form of vp_process_blocks_device (offline rendering from a host program without device allocations of
@@ -1398,7 +1443,7 @@ extern "C" int vp_process_blocks(vp_handle *h, const float *in, float *out, int 
         b += nb;
     }
     HIPCHK(h, hipStreamSynchronize(h->ownStream));
-    return VP_OK;
+    return check_fault(h);                                                    // (behind the synchronisation: this call's own launches included)
 }
 
 // Sizes everything the multi-block entry points need for calls of up to n_blocks blocks.  The ONLY allocation site besides prepare.
@@ -1449,7 +1494,7 @@ extern "C" int vp_process_block(vp_handle *h, const float *in, float *out)
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(out, h->stageOut, nOut * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
     HIPCHK(h, hipStreamSynchronize(h->ownStream));
-    return VP_OK;
+    return check_fault(h);                                                    // (behind the synchronisation: this call's own launches included)
 }
 
 extern "C" int vp_process_block_inplace(vp_handle *h, float *io)
@@ -1463,7 +1508,7 @@ extern "C" int vp_process_block_inplace(vp_handle *h, float *io)
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(io, h->stageOut, n * sizeof(float), hipMemcpyDeviceToHost, h->ownStream));
     HIPCHK(h, hipStreamSynchronize(h->ownStream));
-    return VP_OK;
+    return check_fault(h);                                                    // (behind the synchronisation: this call's own launches included)
 }
 
 extern "C" int vp_get_latency(const vp_handle *h) { return (h && h->prepared) ? h->g.latency : VP_ERR_NOT_PREPARED; }
@@ -1485,6 +1530,18 @@ extern "C" int vp_synchronize(vp_handle *h)
     if (!h) return VP_ERR_INVALID_ARG;
     if (hipSetDevice(h->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     HIPCHK(h, hipDeviceSynchronize());
+    if (h->poisoned) return poisoned_rc(h);
+    return check_fault(h);                                                    // every launch so far has completed: the verdict is final
+}
+
+// Diagnostic: the number of polls a kernel's bounded inter-wavefront wait makes before it gives up (default 2^22, about a second).
+// tests/test_gpu_round6.py sets it to 1 to force the timeout path: the call that synchronises behind such a launch must return
+// VP_ERR_TIMEOUT and leave the handle poisoned.
+extern "C" int vp_debug_set_spin_limit(vp_handle *h, int polls)
+{
+    if (!h || polls < 1) return VP_ERR_INVALID_ARG;
+    h->spinLimit = polls;
+    h->d.spinLimit = polls;
     return VP_OK;
 }
 
@@ -1605,6 +1662,7 @@ struct vp_stft {
     int device, F, hop, S, T, nFrames;
     double *win = nullptr, *tw1 = nullptr, *tw2 = nullptr, *tws = nullptr, *twTop = nullptr;
     float scale;
+    bool pvOk = false;                // the phase-vocoder build's dynamic-LDS ceiling could be raised on this device (vp_stft_pitch_shift needs it)
     int runsPerStream = 0;            // 0: chosen from the batch so that the grid fills the chip; > 0: vp_stft_set_runs (tests)
     int f32 = 0;                      // vp_stft_set_precision
 };
@@ -1623,8 +1681,13 @@ extern "C" int vp_stft_create(int device, int n_streams, int n_samples, int fram
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VP_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return VP_ERR_NO_DEVICE;
-    if (vp_stft_prepare_device() != hipSuccess) return VP_ERR_HIP;          // per handle and device (hipFuncSetAttribute is per device)
     vp_stft *p = new vp_stft();
+    // The phase-vocoder build needs more than the default 64 KB of dynamic LDS: its ceiling is raised per handle and device
+    // (hipFuncSetAttribute acts on the current device).  Only vp_stft_pitch_shift needs it, so a failure is remembered and fails
+    // THAT call; the plain and single-precision round trips (<= 64 KB) are served regardless.  The sticky HIP error is cleared so
+    // that a later hipGetLastError() behind a launch does not report this one.
+    p->pvOk = vp_stft_prepare_device() == hipSuccess;
+    if (!p->pvOk) (void)hipGetLastError();
     p->device = device; p->F = frame_len; p->hop = hop; p->S = n_streams; p->T = n_samples;
     p->nFrames = (n_samples - frame_len) / hop + 1;
     const double PI = 3.141592653589793238;
@@ -1726,6 +1789,7 @@ extern "C" int vp_stft_pitch_shift(vp_stft *p, const float *d_in, float *d_out, 
 {
     if (!p || !d_in || !d_out || !(semitones >= -12.0 && semitones <= 12.0)) return VP_ERR_INVALID_ARG;
     if (p->F != 1024) return VP_ERR_GEOMETRY;                  // the phase-vocoder stage is built for 1024-point frames
+    if (!p->pvOk) return VP_ERR_HIP;                           // (its dynamic-LDS ceiling could not be raised on this device: vp_stft_create)
     if (hipSetDevice(p->device) != hipSuccess) return VP_ERR_NO_DEVICE;
     return stft_fused(p, d_in, d_out, nullptr, (hipStream_t)hip_stream, true, std::pow(2.0, semitones / 12.0));
 }

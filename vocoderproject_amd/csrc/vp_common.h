@@ -128,6 +128,10 @@ struct VpDev {
     // the call and its overlap-add/emit kernel takes pLin in
     int *gateB;              // [V2_MB_MAX][S][2]
     double *pLin;            // [S][pLinLen]
+    unsigned int *fault;     // ONE word of pinned host memory (device address): a bounded inter-wavefront wait that ran out raises it
+                             // (vp_timeout, vp_kernels.hip); the host looks at it on every process call and after every
+                             // synchronisation of its own, fails the call with VP_ERR_TIMEOUT and poisons the handle
+    int spinLimit;           // polls a bounded wait makes before it gives up (2^22 ~ a second; vp_debug_set_spin_limit shortens it for the test)
     const int *streamMap;    // launch of a cohort (streams whose pitchBool/vocBool histories differ from the others'):
                              // workgroup b serves stream streamMap[b]; nullptr (the normal case): stream b
 };

@@ -40,6 +40,19 @@ typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) int lds_i32;
 
+// A bounded inter-wavefront wait ran out (a lost signal, or a wavefront held up for ~a second by a debugger / preemption): the data
+// it waited for is not there, so whatever the launch produces is INVALID.  Counted in dbg[slot] (vp_debug_read_stamps) and raised in
+// the handle's fault word in pinned host memory, where the host finds it at its next look (vp_capi.hip check_fault): the call fails
+// with VP_ERR_TIMEOUT and the handle is poisoned.  The reference asserts on impossible state (PitchProcess.cpp:824,828); this is
+// the batch's counterpart.  One lane calls.
+struct VpTmo { unsigned long long *ctr; unsigned int *fault; int limit; };
+__device__ __forceinline__ VpTmo vp_tmo(const VpDev &d, int slot) { VpTmo t; t.ctr = &d.dbg[slot]; t.fault = d.fault; t.limit = d.spinLimit; return t; }
+__device__ __forceinline__ void vp_timeout(const VpTmo &t, int slot = 61)
+{
+    atomicAdd(t.ctr, 1ULL);
+    if (t.fault) __hip_atomic_store(t.fault, (unsigned)(0x100 | slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Diagnostic build only (-DVP_STAMPS): workgroup 0 / thread 0 accumulates, per phase id, the
 // 100 MHz wall-clock ticks spent since the previous stamp into d.dbg[id].  No stamp executes in
 // the product build.

@@ -113,6 +113,8 @@ def load_library():
     if hasattr(L, "vp_set_wave_specialised"):
         L.vp_set_wave_specialised.argtypes = [C.c_void_p, C.c_int]
         L.vp_get_wave_specialised.argtypes = [C.c_void_p]
+    if hasattr(L, "vp_debug_set_spin_limit"):          # (ABI version 3)
+        L.vp_debug_set_spin_limit.argtypes = [C.c_void_p, C.c_int]
     L.vp_read_ub_counters.argtypes = [vp, C.POINTER(C.c_long)]
     L.vp_debug_read_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     L.vp_set_yin_mode.argtypes = [vp, C.c_int]
@@ -402,6 +404,10 @@ class BatchVocoderProcessor:
 
     def pitch_kernel_name(self):
         return self.L.vp_pitch_kernel_name(self.h).decode()
+
+    def debug_set_spin_limit(self, polls):
+        """Diagnostic: polls a kernel's bounded inter-wavefront wait makes before it raises VP_ERR_TIMEOUT (default 2^22)."""
+        self._chk(self.L.vp_debug_set_spin_limit(self.h, int(polls)))
 
     def vocoder_kernel_name(self):
         return self.L.vp_vocoder_kernel_name(self.h).decode()
