@@ -24,7 +24,11 @@ run() {
 }
 sel=${2:-all}
 [ $sel = all -o $sel = cfg2 ] && run cfg2_pitch_s256
-[ $sel = all -o $sel = cfg3 ] && run cfg3_voc_s256 --mode voc
+# configs[2] AS BENCHED (bench.py's configs2 legs): lpcVoice 24 on the reference's 512/128 window and on the metric's 1024/256 window
+[ $sel = all -o $sel = cfg3 ] && run cfg3_voc_s256_lpc24 --mode voc --lpc-voice 24
+[ $sel = all -o $sel = cfg3 ] && run cfg3_voc_s256_lpc24_w1024 --mode voc --lpc-voice 24 --voc-window 1024/256
+# the +-12-semitone leg of configs[1]
+[ $sel = all -o $sel = cfg2s ] && run cfg2_pitch_s256_pm12 --shift 12
 [ $sel = all -o $sel = cfg4 ] && run cfg4_both_s1024 --mode both --streams 1024
 [ $sel = all -o $sel = cfg5 ] && run cfg5_both_s512 --cfg5 --mode both --streams 512
 [ $sel = all -o $sel = cfg2x ] && run cfg2_pitch_s256_exact --iir exact

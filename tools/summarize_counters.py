@@ -61,7 +61,7 @@ def main():
         except (OSError, ValueError, IndexError):
             continue
         cfg = line["config"]
-        if line.get("stft_only"):
+        if line.get("stft_only") or cfg.get("workload_key"):
             wkey = cfg["workload_key"]
         else:
             mono = cfg["input"].startswith("mono")
