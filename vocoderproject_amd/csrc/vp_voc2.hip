@@ -177,12 +177,27 @@ __global__ __launch_bounds__(256) void vp_k_v2_ingest_stage(VpGeom g, VpCall c, 
 // per workgroup: they are latency-bound (two of their wavefronts on a SIMD overlap) or have several wavefronts per SIMD anyway --
 // vp_k_v2_iir_fast 31.1 -> 30.8 us, vp_k_v2_fir2 16.8 -> 17.0, vp_k_v2_levinson2 12.3 -> 12.4, vp_k_v2_iir_exact<40> 157 -> 162.
 #define V2_AC_WAVES 4
+// Round 6, VP_IIR_FAST: the workgroup's four wavefronts are four STRETCHES of n of ONE (window group, lag group) instead of four window
+// groups: stretch p takes the main loop's samples [p S8, (p + 1) S8), S8 = W / 4 rounded up to whole 8-sample trips, the last one also
+// the tail; the four partial sums of a lag meet in LDS and are added in stretch order.  Few, long windows (configs[4]: 2048 windows of
+// 2048 samples) gave this kernel 672 wavefronts of 256 trips each -- 63 us on 1024 SIMDs; this way it has four times the wavefronts, a
+// quarter as long.  Which terms meet in which partial sum depends on the window length alone (not on the orders or on how many
+// windows a launch carries), so a stream's tolerance-mode bits do not depend on its neighbours.
+// (Measured on the way, same box, rocprofv3: stretches as a grid dimension whose partial sums meet in HBM -- the LAST workgroup of a cell,
+// found by a counter behind __threadfence(), adds them -- cost 60 us PER FENCE LEVEL: an agent-scope release/acquire on this chip writes
+// back and invalidates an XCD's whole L2.  Twenty-four lags per wavefront (a 32-entry register ring, a third of the tile traffic):
+// 197 registers, 99 us against 27 -- fewer, longer wavefronts wait longer for the same loads.  The lag groups of one window group as
+// the four wavefronts of a workgroup, for L1 hits on the shared tile rows: 35 against 33 us.)
+// VP_IIR_EXACT keeps the single left-to-right sum per lag: four window groups per workgroup.
 template <int L, bool FS = false>
 __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, VpCall c, VpDev d, VpV2 v)
 {
     static_assert(L == 4 || L == 8, "lag groups of 4 or 8");
     extern __shared__ double smem[];
-    const int lane = threadIdx.x & 63, w = (blockIdx.x * V2_AC_WAVES + (threadIdx.x >> 6)) * WAVE + lane;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform FOR THE COMPILER too: the stretch's bounds index scalar loads)
+    constexpr int nP = FS ? V2_AC_WAVES : 1;                               // stretches (FS: one per wavefront of the workgroup)
+    const int pz = FS ? wv : 0;
+    const int lane = threadIdx.x & 63, w = (FS ? (int)blockIdx.x : (int)blockIdx.x * V2_AC_WAVES + wv) * WAVE + lane;
     const int gV = (v.oVmax + L) / L;                                     // lag groups of the voice: ceil((oVmax + 1) / L)
     const bool isS = (int)blockIdx.y >= gV;
     const int m0 = (isS ? (int)blockIdx.y - gV : (int)blockIdx.y) * L;
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, V
     lds_f64 *wl = (lds_f64 *)smem;
     for (int i = threadIdx.x; i < W + 16; i += 64 * V2_AC_WAVES) wl[i] = (i < W) ? d.vocWin[i] : 0.0;
     __syncthreads();
-    if (!__any(q.live)) return;
+    if (!__any(q.live)) return;                                              // (FS: the four wavefronts see the same windows -- all leave or none)
     const V2X x = v2_x(v, isS ? 1 : 0, q.b * c.nWin + q.j);
     double sum[L];
 #pragma unroll
@@ -201,7 +216,10 @@ __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, V
     // all L lags are inside the window while n + m0 + L - 1 < W
     const int nAll = max(0, W - m0 - (L - 1));
     const int nMain = nAll & ~7;
-    if (nMain > 0) {
+    // this wavefront's stretch of the main loop: fixed sample positions (a function of W alone)
+    const int S8 = ((W / nP) + 7) & ~7;
+    const int nLo = FS ? min(nMain, pz * S8) : 0, nHi = (!FS || pz == nP - 1) ? nMain : min(nMain, (pz + 1) * S8);
+    if (nHi > nLo) {
         // The lane's samples x[n + m0 + q] slide through a RING of sixteen registers (static names: two trips of eight steps per
         // loop iteration, the second one half a ring further on), eight new ones per trip; those and the eight samples of
         // tmp = x[n] w[n] are requested one trip ahead (aligned 16-byte loads, contiguous across the lanes; the last trip
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, V
 #define V2_AC_WIN(I) wg[I]
         double R[16];
 #pragma unroll
-        for (int t = 0; t < L; t++) R[t] = FS ? (double)x[m0 + t] * V2_AC_WIN(m0 + t) : (double)x[m0 + t];
+        for (int t = 0; t < L; t++) R[t] = FS ? (double)x[nLo + m0 + t] * V2_AC_WIN(nLo + m0 + t) : (double)x[nLo + m0 + t];
         float4 au0, au1, ax0, ax1, bu0, bu1, bx0, bx1, cu0, cu1, cx0, cx1, du0, du1, dx0, dx1;
 #define V2_AC_LOAD(U0, U1, X0, X1, N) { U0 = *(const float4 *)&x.base[(size_t)((N) >> 2) * 256]; U1 = *(const float4 *)&x.base[(size_t)(((N) >> 2) + 1) * 256]; \
         X0 = *(const float4 *)&x.base[(size_t)(((N) + m0 + L) >> 2) * 256]; X1 = *(const float4 *)&x.base[(size_t)((((N) + m0 + L) >> 2) + 1) * 256]; }
@@ -239,24 +257,24 @@ __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, V
                 else { double p = u[t] * R[(t + j + PH) & 15]; p = p * WX[t + j]; sum[j] += p; } } } }
         // (requests run TWO trips ahead -- four named buffer sets, four trips per loop iteration: with one or two wavefronts
         // per SIMD a trip of 0.2-0.4 us does not cover a memory round trip)
-        V2_AC_LOAD(au0, au1, ax0, ax1, 0)
-        V2_AC_LOAD(bu0, bu1, bx0, bx1, 8)
-        V2_AC_WLOAD(wuA, wxA, 0)
-        for (int n = 0; n < nMain; n += 32) {
+        V2_AC_LOAD(au0, au1, ax0, ax1, nLo)
+        V2_AC_LOAD(bu0, bu1, bx0, bx1, nLo + 8)
+        V2_AC_WLOAD(wuA, wxA, nLo)
+        for (int n = nLo; n < nHi; n += 32) {
             V2_AC_LOAD(cu0, cu1, cx0, cx1, n + 16)
             V2_AC_WLOAD(wuB, wxB, n + 8)
             V2_AC_TRIP(0, au0, au1, ax0, ax1, n, wuA, wxA)
-            if (n + 8 < nMain) {
+            if (n + 8 < nHi) {
                 V2_AC_LOAD(du0, du1, dx0, dx1, n + 24)
                 V2_AC_WLOAD(wuA, wxA, n + 16)
                 V2_AC_TRIP(8, bu0, bu1, bx0, bx1, n + 8, wuB, wxB)
             }
-            if (n + 16 < nMain) {
+            if (n + 16 < nHi) {
                 V2_AC_LOAD(au0, au1, ax0, ax1, n + 32)
                 V2_AC_WLOAD(wuB, wxB, n + 24)
                 V2_AC_TRIP(0, cu0, cu1, cx0, cx1, n + 16, wuA, wxA)
             }
-            if (n + 24 < nMain) {
+            if (n + 24 < nHi) {
                 V2_AC_LOAD(bu0, bu1, bx0, bx1, n + 40)
                 V2_AC_WLOAD(wuA, wxA, n + 32)
                 V2_AC_TRIP(8, du0, du1, dx0, dx1, n + 24, wuB, wxB)
@@ -267,6 +285,7 @@ __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, V
 #undef V2_AC_WLOAD
 #undef V2_AC_WIN
     }
+    if (pz == nP - 1)
     for (int n = nMain; n < W - m0; n++) {                                  // the last steps: lags drop out one by one
         const double u = (double)x[n] * wl[n];
 #pragma unroll
@@ -281,9 +300,27 @@ __global__ __launch_bounds__(64 * V2_AC_WAVES) void vp_k_v2_autocorr(VpGeom g, V
             }
         }
     }
-    if (q.live) {
-        const V2Col r = isS ? v2_col(v.rS, V2_RS_STRIDE, w) : v2_col(v.rV, V2_RV_STRIDE, w);
-        const int top = isS ? VP_ORDER_MAX_SYNTH : VP_ORDER_MAX;
+    const V2Col r = isS ? v2_col(v.rS, V2_RS_STRIDE, w) : v2_col(v.rV, V2_RV_STRIDE, w);
+    const int top = isS ? VP_ORDER_MAX_SYNTH : VP_ORDER_MAX;
+    if (FS) {
+        // the four stretches' partial sums meet in LDS (behind the window function's copy; the tail is done with it) and are added in
+        // stretch order: wavefront p adds lags j = p, p + 4, ... (LPC.cpp:93-96's division on the total)
+        lds_f64 *ps = (lds_f64 *)smem + ((W + 16 + 1) & ~1);
+#pragma unroll
+        for (int j = 0; j < L; j++) ps[(pz * L + j) * WAVE + lane] = sum[j];
+        __syncthreads();
+        if (q.live) {
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                if ((j & (nP - 1)) == pz && m0 + j <= top) {
+                    double s = ps[(0 * L + j) * WAVE + lane];
+#pragma unroll
+                    for (int p = 1; p < nP; p++) s += ps[(p * L + j) * WAVE + lane];
+                    r[m0 + j] = s / (double)W;
+                }
+            }
+        }
+    } else if (q.live) {
 #pragma unroll
         for (int j = 0; j < L; j++)
             if (m0 + j <= top) r[m0 + j] = sum[j] / (double)W;           // :93-96
@@ -960,16 +997,22 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
     // wavefronts are then alone on their SIMDs and half as long --, eight beyond that)
     static const int nCus = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     const int wgs4 = ((nGroups + V2_AC_WAVES - 1) / V2_AC_WAVES) * ((v.oVmax + 4) / 4 + (v.oSmax + 4) / 4);
-    if (forceL ? forceL == 8 : wgs4 > nCus) {
+    if (c.iirFast && v2_ac_fs()) {
+        // (round 6) the workgroup's wavefronts are the four stretches of one (window group, lag group): grid = window groups x lag groups,
+        // eight lags per wavefront; + LDS for the partial sums [4][L][64]
+        const int L = (forceL == 4) ? 4 : 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
+        const dim3 ga(nGroups, gy), ba(64 * V2_AC_WAVES);
+        const size_t lds = (size_t)(((g.W + 16 + 1) & ~1) + V2_AC_WAVES * L * 64) * 8;
+        if (L == 8) V2_LAUNCH((vp_k_v2_autocorr<8, true>), ga, ba, lds, g, c, d, v);
+        else V2_LAUNCH((vp_k_v2_autocorr<4, true>), ga, ba, lds, g, c, d, v);
+    } else if (forceL ? forceL == 8 : wgs4 > nCus) {
         const int L = 8, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
         const dim3 ga((nGroups + V2_AC_WAVES - 1) / V2_AC_WAVES, gy), ba(64 * V2_AC_WAVES);
-        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<8, true>), ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
-        else V2_LAUNCH(vp_k_v2_autocorr<8>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
+        V2_LAUNCH(vp_k_v2_autocorr<8>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
     } else {
         const int L = 4, gy = (v.oVmax + L) / L + (v.oSmax + L) / L;
         const dim3 ga((nGroups + V2_AC_WAVES - 1) / V2_AC_WAVES, gy), ba(64 * V2_AC_WAVES);
-        if (c.iirFast && v2_ac_fs()) V2_LAUNCH((vp_k_v2_autocorr<4, true>), ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
-        else V2_LAUNCH(vp_k_v2_autocorr<4>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
+        V2_LAUNCH(vp_k_v2_autocorr<4>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
     }
     v2_launch_lpc_fir(v.oVmax, v.oSmax, nGroups, g.W, st, g, c, d, v);
     if (c.iirFast) {
