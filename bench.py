@@ -444,8 +444,9 @@ def main():
     ap.add_argument("--voc-path", default="auto", choices=["auto", "workgroup", "batched"],
                     help="vocoder implementation (vp_set_vocoder_path): one workgroup per stream, or the lane-per-window pipeline "
                          "(auto: the pipeline above 256 streams)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="combined mode, FAST, batched vocoder: run the pitch corrector beside the vocoder pipeline instead of behind it (vp_set_overlap)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="combined mode, FAST, batched vocoder: the pitch corrector beside the vocoder pipeline's tail instead of behind it "
+                         "(vp_set_overlap; auto = the library's default: where the pitch build leaves registers beside it)")
     ap.add_argument("--lpc-voice", type=int, default=None,
                     help="lpcVoice (the plugin's default is 40; BASELINE configs[2] names 24)")
     ap.add_argument("--voc-window", default=None, choices=["512/128", "1024/256"],
@@ -531,7 +532,7 @@ def main():
             q.prepareToPlay(FS, N, S_)
         q.set_yin_mode(args.yin)
         q.set_vocoder_path(args.voc_path)
-        q.set_overlap(args.overlap)
+        q.set_overlap({"auto": "auto", "on": True, "off": False}[args.overlap])
         return q
 
     p = make_processor(mode, S)

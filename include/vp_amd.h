@@ -196,11 +196,14 @@ int vp_get_iir_mode(const vp_handle *h);
 int vp_set_vocoder_path(vp_handle *h, int path);
 int vp_get_vocoder_path(const vp_handle *h);
 
-/* VP_IIR_FAST only, both processes on, batched vocoder: run the pitch corrector BESIDE the vocoder pipeline (second HIP stream,
- * accumulator of its own, merged at emit) instead of behind it.  OFF by default (measured: +1 % at 1024 streams, -7 % at the
- * configs[4] geometry -- the pitch kernel's resident workgroups leave no registers for anything beside them).  What is given up is the order in which
- * the two processes' contributions are added into the output accumulator (PluginProcessor.cpp:214-221), i.e. rounding; the
- * exact mode never does this.  A caller's hip_stream is respected: the work it sees is ordered on that stream. */
+/* VP_IIR_FAST only, both processes on, batched vocoder: run the pitch corrector BESIDE the tail of the vocoder pipeline (its all-pole
+ * recursion and overlap-add: register-light kernels that fit into what the pitch kernel leaves of a SIMD's register file; second
+ * HIP stream, accumulator of its own, merged at emit) instead of behind it.  0 off, 1 on, VP_OVERLAP_AUTO (the default): on where it
+ * pays -- the full-register pitch builds (frames too large for two workgroups per CU: 419 -> 376 us per block at the configs[4]
+ * geometry), off for the register-light ones (1024 streams of the plugin's geometry: 276 against 274 us).  What is given up is the
+ * order in which the two processes' contributions are added into the output accumulator (PluginProcessor.cpp:214-221), i.e.
+ * rounding; the exact mode never does this.  A caller's hip_stream is respected: the work it sees is ordered on that stream. */
+#define VP_OVERLAP_AUTO 2
 int vp_set_overlap(vp_handle *h, int on);
 int vp_get_overlap(const vp_handle *h);
 /* SURVEY 8(f2), time-parallel pitch front end (off by default).  With the switch on, a multi-block call (vp_process_blocks[_mono]_device,

@@ -541,7 +541,7 @@ def test_pitch_beside_vocoder_equals_pitch_behind_vocoder(S, path):
             ys.append(p.process(np.ascontiguousarray(x[:, :, b * N:(b + 1) * N])))
         return np.concatenate(ys, axis=2), [p.pitch_state(s_) for s_ in range(min(S, U))]
 
-    assert BatchVocoderProcessor().L.vp_get_overlap(BatchVocoderProcessor().h) == 0      # off by default
+    assert BatchVocoderProcessor().L.vp_get_overlap(BatchVocoderProcessor().h) == 2      # VP_OVERLAP_AUTO by default
     seq, st_seq = run("fast", lambda b: False)
     par, st_par = run("fast", lambda b: True)
     mix, _ = run("fast", lambda b: (b // 3) % 2 == 0)

@@ -59,12 +59,11 @@ struct vp_handle {
     std::vector<void *> bothAllocs;
     // vp_set_overlap(h, 1), VP_IIR_FAST, both processes on, batched vocoder: the pitch kernel runs beside the vocoder pipeline on
     // auxStream and adds into its own accumulator (acc2), which emit merges.  acc2Live: blocks for which acc2 may still hold
-    // something.  Off by default: measured 404 vs 408 us per block at 1024 streams, 880 vs 820 us at the configs[4] geometry --
-    // two resident pitch workgroups fill a CU's registers, so the two launches mostly take turns.
+    // something.  VP_OVERLAP_AUTO (default): where the pitch build leaves registers beside it (process_device).
     hipStream_t auxStream = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     double *acc2 = nullptr;
-    int overlap = 0, acc2Live = 0;
+    int overlap = VP_OVERLAP_AUTO, acc2Live = 0;
     int waveSpec = 1;                           // vp_set_wave_specialised: vp_k_pitch_ws* where they apply (pitch_ws_ok)
     int timeParallel = 0;                       // vp_set_time_parallel: multi-block pitch launches behind the analysis front end (vp_k_pitch_front)
     std::vector<void *> allocs;
@@ -288,8 +287,8 @@ extern "C" int vp_set_vocoder_path(vp_handle *h, int path)
 extern "C" int vp_get_vocoder_path(const vp_handle *h) { return h ? h->vocPath : VP_ERR_INVALID_ARG; }
 extern "C" int vp_set_overlap(vp_handle *h, int on)
 {
-    if (!h) return VP_ERR_INVALID_ARG;
-    h->overlap = on ? 1 : 0;
+    if (!h || on < 0 || on > VP_OVERLAP_AUTO) return VP_ERR_INVALID_ARG;
+    h->overlap = on;
     return VP_OK;
 }
 extern "C" int vp_get_overlap(const vp_handle *h) { return h ? h->overlap : VP_ERR_INVALID_ARG; }
@@ -967,10 +966,17 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
             { ProfScope ps(h, st, 3); hipLaunchKernelGGL(vp_k_emit, dim3(co.n), dim3(256), 0, st, g, c, d, d_out); }
         } else {
             const bool batched = runVoc && voc_batched_for(h, c.nWin, co.oVmax, co.oSmax);
-            if (batched && runPitch && c.iirFast && h->overlap && nBlocks == 1) {
-                // VP_IIR_FAST (tolerance mode), both processes, batched vocoder: the pitch kernel starts on a second HIP stream
-                // as soon as the input is in the rings and the gate is known, and adds into an accumulator of its own; the
-                // vocoder pipeline's serial stages occupy few SIMDs, the pitch kernel's serial phases leave issue slots free.
+            if (batched && runPitch && c.iirFast && nBlocks == 1 && (h->overlap == 1 || (h->overlap == VP_OVERLAP_AUTO && !pitch_lite(h, true)))) {
+                // VP_IIR_FAST (tolerance mode), both processes, batched vocoder: the pitch kernel runs on a second HIP stream BESIDE
+                // the pipeline's last two kernels and adds into an accumulator of its own.  (Round 6) the fork sits behind the
+                // residual kernel: autocorrelation, Levinson-Durbin and the residual FIRs need 130-300 registers per wavefront and
+                // would only take turns with the pitch workgroups; vp_k_v2_iir_fast (64 registers, no LDS, a serial chain per window
+                // that leaves half the chip idle at the configs[4] geometry) and vp_k_v2_ola (26) fit into what the pitch
+                // full-register builds leave of every SIMD's register file (vp_k_pitch_fast: 2 x 224 of 512), so they run in its shadow:
+                // configs[4] geometry 419 -> 376 us per block (same box).  The register-light builds fill the file (4 x 128): a 112-register
+                // build of vp_k_pitch_lite_fast_c (13 spills) did hide the two kernels, but ran 10 us longer itself, and the plan's own
+                // costs -- the separate emit kernel, two cross-stream waits -- ate the rest: 276 against 274 us at 1024 streams.  So
+                // VP_OVERLAP_AUTO (the default) takes this plan for the full-register builds only.
                 // What is given up is the ORDER of the additions into the output accumulator (windows, then chunks, per
                 // block: PluginProcessor.cpp:214-221) -- rounding-level; VP_IIR_EXACT keeps the sequential plan below.
                 struct Fork { vp_handle *h; hipStream_t st; VpGeom g; VpCall cp; VpDev dp; const float *in; float *out; int n; hipError_t err; } fk;

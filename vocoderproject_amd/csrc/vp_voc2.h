@@ -38,6 +38,7 @@ struct VpV2MB { int nBlocks, vStart[V2_MB_MAX], nWin[V2_MB_MAX], first[V2_MB_MAX
 int vp_v2_init();
 void vp_v2_launch_blocks(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const VpV2MB &mb, const float *d_in, float *d_out,
                          hipStream_t st);
-// `afterIngest` (optional) is called right behind the launch of the ingest+gate+stage kernel (what the caller wants to start beside the rest)
+// `beforeIir` (optional) is called right behind the launch of the residual kernel, in front of the recursion's (what the caller wants to start beside
+// the pipeline's register-light tail: vp_k_v2_iir_fast, vp_k_v2_ola)
 void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, const float *d_in, float *d_out, hipStream_t st,
-                  void (*afterIngest)(void *) = nullptr, void *hookArg = nullptr);
+                  void (*beforeIir)(void *) = nullptr, void *hookArg = nullptr);

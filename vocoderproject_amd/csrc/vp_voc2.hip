@@ -987,10 +987,10 @@ int vp_v2_init()
 static bool v2_ac_fs() { static const bool on = !getenv("VP_V2_NO_AC_FS"); return on; }   // (diagnostic switch for A/B runs)
 
 // autocorrelation ... all-pole output for the NW = nStreams x c.nWin windows the stage kernel has laid out
-static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, hipStream_t st)
+static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, hipStream_t st, void (*beforeIir)(void *) = nullptr, void *hookArg = nullptr)
 {
     const int NW = v.nStreams * c.nWin, nGroups = (NW + 63) / 64;
-    if (NW <= 0) return;
+    if (NW <= 0) { if (beforeIir) beforeIir(hookArg); return; }
     // few, long windows: fewer lags per wave so that there are enough waves (the n loop is serial)
     static const int forceL = getenv("VP_V2_AC_L") ? atoi(getenv("VP_V2_AC_L")) : 0;     // (diagnostic)
     // (round 4, with the wavefronts placed evenly: four lags per wavefront while those workgroups still get a CU each -- the
@@ -1015,6 +1015,7 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
         V2_LAUNCH(vp_k_v2_autocorr<4>, ga, ba, (size_t)(g.W + 16) * 8, g, c, d, v);
     }
     v2_launch_lpc_fir(v.oVmax, v.oSmax, nGroups, g.W, st, g, c, d, v);
+    if (beforeIir) beforeIir(hookArg);                                     // (the caller forks what is to run beside the recursion and the overlap-add)
     if (c.iirFast) {
         // (the window energies and gains are formed inside the recursion kernel: v2_gain_row)
         // (two windows per row interleaved, NI = 2, was tried for few, long windows: 82 -> 133 us at the configs[4] geometry)
@@ -1037,14 +1038,13 @@ static void v2_launch_middle(const VpGeom &g, const VpCall &c, const VpDev &d, c
 }
 
 void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v_, const float *d_in, float *d_out, hipStream_t st,
-                  void (*afterIngest)(void *), void *hookArg)
+                  void (*beforeIir)(void *), void *hookArg)
 {
     const VpV2 &v = v_;
     // the staged stretch of the ring through LDS when two channels of it fit beside the kernel's static LDS (else straight from the ring)
     const int span = (c.nWin - 1) * g.h + g.W, spanLds = (c.nWin > 0 && (size_t)2 * span * sizeof(float) <= 40 * 1024) ? ((span + 3) & ~3) : 0;
     V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), (size_t)2 * spanLds * sizeof(float), g, c, d, v, d_in, spanLds);
-    if (afterIngest) afterIngest(hookArg);
-    v2_launch_middle(g, c, d, v, st);
+    v2_launch_middle(g, c, d, v, st, beforeIir, hookArg);
     V2_LAUNCH(vp_k_v2_ola, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_out);
 }
 

@@ -222,7 +222,7 @@ class BatchVocoderProcessor:
 
     def set_overlap(self, on):
         """FAST mode, both processes, batched vocoder: pitch corrector beside the vocoder pipeline (default) or behind it."""
-        self._chk(self.L.vp_set_overlap(self.h, int(bool(on))))
+        self._chk(self.L.vp_set_overlap(self.h, 2 if on == "auto" else int(bool(on))))
 
     def set_time_parallel(self, on):
         """Multi-block pitch-only calls behind the time-parallel analysis front end (vp_k_pitch_front; off by default, see include/vp_amd.h)."""
