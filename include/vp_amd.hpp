@@ -97,8 +97,10 @@ public:
 
     // which implementation runs VocoderProcess::process (VP_VOC_AUTO / VP_VOC_WORKGROUP / VP_VOC_BATCHED; same results)
     void setVocoderPath(int path) { check(vp_set_vocoder_path(h_, path), "setVocoderPath"); }
-    // VP_IIR_FAST: pitch corrector beside the vocoder pipeline instead of behind it (off by default)
-    void setOverlap(bool on) { check(vp_set_overlap(h_, on ? 1 : 0), "setOverlap"); }
+    // VP_IIR_FAST: pitch corrector beside the vocoder pipeline's tail instead of behind it: 0 / 1 / VP_OVERLAP_AUTO (the default)
+    void setOverlap(int mode) { check(vp_set_overlap(h_, mode), "setOverlap"); }
+    void setIirMode(int mode) { check(vp_set_iir_mode(h_, mode), "setIirMode"); }
+    void setYinMode(int mode) { check(vp_set_yin_mode(h_, mode), "setYinMode"); }
 
     void prepareToPlay(double sampleRate, int samplesPerBlock, int nStreams)      // PluginProcessor.cpp:144
     {
@@ -138,6 +140,9 @@ public:
     // the same from host memory (upload, the blocks, download, in groups of the reserved size)
     void processBlocks(const float *in, float *out, int nBlocks) { check(vp_process_blocks(h_, in, out, nBlocks), "processBlocks"); }
     int getLatencySamples() const { return vp_get_latency(h_); }                   // :183
+    // waits for everything launched on the handle's device and reports what poisoned the handle, if anything (VP_ERR_TIMEOUT: a
+    // kernel's bounded wait ran out): the call a host makes before it trusts what the device-pointer entry points produced
+    void synchronize() { check(vp_synchronize(h_), "synchronize"); }
     BufferView bufferView() const
     {
         BufferView v;
@@ -226,9 +231,39 @@ public:
     }
     int getLatencySamples() const { return shards_[0]->proc.getLatencySamples(); }
 
+    // ---- device-resident, asynchronous forms (the rate bench.py reports is reached with inputs resident in HBM) -----------------------
+    // Every shard's buffers live on ITS device: dIn[g] = [shardRange(g).second][3][N] floats on device devices[g], dOut[g] likewise
+    // with 2 channels; hipStreams[g] (optional) a stream of that device.  The calls ENQUEUE shard g's kernels from shard g's worker
+    // thread -- side by side, the handles' host work included -- and return when all are enqueued, not when they have run:
+    // synchronize() (or the caller's own stream synchronisation followed by synchronize()) before the output is read.
+    void processBlockDevice(const float *const *dIn, float *const *dOut, void *const *hipStreams = nullptr)
+    {
+        run([&](int g, Shard &sh) { sh.proc.processBlockDevice(dIn[g], dOut[g], hipStreams ? hipStreams[g] : nullptr); });
+    }
+    void processBlockMonoDevice(const float *const *dVoice, float *const *dOut, void *const *hipStreams = nullptr)   // voice [streams_g][N]
+    {
+        run([&](int g, Shard &sh) { sh.proc.processBlockMonoDevice(dVoice[g], dOut[g], hipStreams ? hipStreams[g] : nullptr); });
+    }
+    // nBlocks queued blocks per call: dIn[g] = [nBlocks][streams_g][3][N] -> dOut[g] = [nBlocks][streams_g][2][N] (reserveBlocks first)
+    void processBlocksDevice(const float *const *dIn, float *const *dOut, int nBlocks, void *const *hipStreams = nullptr)
+    {
+        run([&](int g, Shard &sh) { sh.proc.processBlocksDevice(dIn[g], dOut[g], nBlocks, hipStreams ? hipStreams[g] : nullptr); });
+    }
+    void processBlocksMonoDevice(const float *const *dVoice, float *const *dOut, int nBlocks, void *const *hipStreams = nullptr)
+    {
+        run([&](int g, Shard &sh) { sh.proc.processBlocksMonoDevice(dVoice[g], dOut[g], nBlocks, hipStreams ? hipStreams[g] : nullptr); });
+    }
+    void reserveBlocks(int nBlocks) { run([&](int, Shard &sh) { sh.proc.reserveBlocks(nBlocks); }); }
+    // every shard's device idle, and every shard's verdict (the first error is rethrown: VP_ERR_TIMEOUT / VP_ERR_HIP poison a handle)
+    void synchronize() { run([&](int, Shard &sh) { sh.proc.synchronize(); }); }
+    void setIirMode(int mode) { for (auto &sh : shards_) sh->proc.setIirMode(mode); }
+    void setYinMode(int mode) { for (auto &sh : shards_) sh->proc.setYinMode(mode); }
+    int device(int g) const { return shards_[g]->dev; }
+
 private:
     struct Shard {
         BatchVocoderProcessor proc;
+        int dev;
         std::thread worker;
         std::mutex m;
         std::condition_variable cv;
@@ -241,7 +276,7 @@ private:
             cv.notify_all();
             if (worker.joinable()) worker.join();
         }
-        explicit Shard(int dev) : proc(dev)
+        explicit Shard(int dev_) : proc(dev_), dev(dev_)
         {
             worker = std::thread([this] {
                 std::unique_lock<std::mutex> lk(m);

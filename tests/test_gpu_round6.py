@@ -275,3 +275,102 @@ def test_stft_plain_roundtrip_does_not_depend_on_the_phase_vocoder_attribute():
     torch.cuda.synchronize()
     assert float((x[:, 1024:-1024] - y[:, 1024:-1024]).abs().max()) < 1e-5
     st.close()
+
+
+def test_cpp_sharded_batch_processor_device_resident_forms(tmp_path):
+    """vp::ShardedBatchProcessor's device-pointer forms (round-5 verdict, item 7): processBlockDevice / processBlockMonoDevice /
+    processBlocksDevice with every shard's buffers resident on its device, enqueued from the shards' worker threads, then
+    synchronize().  G = 2 and 3 handles on device 0 against ONE handle driven through the host-pointer entry point: bit for bit,
+    ragged shards, both processes on (single blocks, then three blocks per call), and the pitch corrector alone from mono buffers."""
+    import os
+    import shutil
+    import subprocess
+    from vocoderproject_amd import build
+    gxx = shutil.which("g++")
+    if not gxx or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no g++ / HIP headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = build.build()
+    src = tmp_path / "t.cpp"
+    src.write_text(r"""
+#include <hip/hip_runtime_api.h>
+#include "vp_amd.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#define HIPOK(x) do { if ((x) != hipSuccess) { std::printf("HIP error at %d\n", __LINE__); return 9; } } while (0)
+int main() {
+    const int S = 7, N = 1024, B = 12;
+    std::vector<float> x((size_t)B * S * 3 * N);
+    unsigned lcg = 777u;
+    for (int b = 0; b < B; b++) for (int s = 0; s < S; s++) for (int c = 0; c < 3; c++) for (int i = 0; i < N; i++) {
+        const double t = (double)(b * N + i) / 44100.0, f0 = 131.0 + 29.0 * s;
+        lcg = lcg * 1664525u + 1013904223u;
+        const double nz = ((double)(lcg >> 8) / 16777216.0 - 0.5) * 0.004;
+        double v = 0.0;
+        if (c == 0) { for (int h = 1; h <= 8; h++) v += std::sin(2.0 * M_PI * h * f0 * t) / h; v = 0.25 * v + nz; }
+        else v = 0.15 * (2.0 * std::fmod(t * (110.0 + 13.0 * s), 1.0) - 1.0);
+        x[(((size_t)b * S + s) * 3 + c) * N + i] = (float)v;
+    }
+    try {
+        for (int mono = 0; mono < 2; mono++) {
+            vp::BatchVocoderProcessor one(0);
+            if (mono) one.setParameter("vocBool", 0);
+            one.prepareToPlay(44100.0, N, S);
+            one.setStreamParameter(2, "keyPitch", 5);
+            std::vector<float> ref((size_t)B * S * 2 * N), got(ref.size(), -1.0f);
+            for (int b = 0; b < B; b++) one.processBlock(&x[(size_t)b * S * 3 * N], &ref[(size_t)b * S * 2 * N]);
+            for (int G = 2; G <= 3; G++) {
+                vp::ShardedBatchProcessor sh(std::vector<int>(G, 0));
+                if (mono) sh.setParameter("vocBool", 0);
+                sh.prepareToPlay(44100.0, N, S);
+                sh.setStreamParameter(2, "keyPitch", 5);
+                sh.reserveBlocks(3);
+                const int C = mono ? 1 : 3;
+                std::vector<float *> dIn(G), dOut(G);
+                std::vector<const float *> dInC(G);
+                for (int g = 0; g < G; g++) {
+                    HIPOK(hipSetDevice(sh.device(g)));
+                    HIPOK(hipMalloc((void **)&dIn[g], (size_t)3 * sh.shardRange(g).second * C * N * sizeof(float)));
+                    HIPOK(hipMalloc((void **)&dOut[g], (size_t)3 * sh.shardRange(g).second * 2 * N * sizeof(float)));
+                    dInC[g] = dIn[g];
+                }
+                // blocks 0 .. 5 one at a time, 6 .. 11 three per call
+                for (int b = 0; b < B; ) {
+                    const int nb = b < 6 ? 1 : 3;
+                    for (int g = 0; g < G; g++) {
+                        const int lo = sh.shardRange(g).first, n = sh.shardRange(g).second;
+                        for (int k = 0; k < nb; k++) for (int s = 0; s < n; s++) for (int c = 0; c < C; c++)
+                            HIPOK(hipMemcpy(dIn[g] + (((size_t)k * n + s) * C + c) * N, &x[((((size_t)(b + k)) * S + lo + s) * 3 + c) * N], N * sizeof(float), hipMemcpyHostToDevice));
+                    }
+                    if (nb == 1) { if (mono) sh.processBlockMonoDevice(dInC.data(), dOut.data()); else sh.processBlockDevice(dInC.data(), dOut.data()); }
+                    else { if (mono) sh.processBlocksMonoDevice(dInC.data(), dOut.data(), nb); else sh.processBlocksDevice(dInC.data(), dOut.data(), nb); }
+                    sh.synchronize();
+                    for (int g = 0; g < G; g++) {
+                        const int lo = sh.shardRange(g).first, n = sh.shardRange(g).second;
+                        for (int k = 0; k < nb; k++)
+                            HIPOK(hipMemcpy(&got[((size_t)(b + k) * S + lo) * 2 * N], dOut[g] + (size_t)k * n * 2 * N, (size_t)n * 2 * N * sizeof(float), hipMemcpyDeviceToHost));
+                    }
+                    b += nb;
+                }
+                for (int g = 0; g < G; g++) { HIPOK(hipFree(dIn[g])); HIPOK(hipFree(dOut[g])); }
+                if (std::memcmp(ref.data(), got.data(), ref.size() * sizeof(float)) != 0) { std::printf("mono %d G = %d differs\n", mono, G); return 5; }
+            }
+            double e = 0.0;
+            for (float v : ref) e += (double)v * v;
+            if (!(e > 0.0)) return 6;
+        }
+        std::printf("sharded device forms == single handle\n");
+        return 0;
+    } catch (const vp::Error &e) {
+        std::printf("vp::Error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+}
+""")
+    exe = tmp_path / "t"
+    subprocess.check_call([gxx, "-std=c++17", "-O1", "-Wall", "-Werror", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe), lib, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.dirname(lib) + ":/opt/rocm/lib", "-lpthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
