@@ -374,3 +374,47 @@ int main() {
                            str(src), "-o", str(exe), lib, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.dirname(lib) + ":/opt/rocm/lib", "-lpthread"])
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+# ---- the plugin's geometry at 48 kHz as bench.py times it --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["pitch", "both"])
+def test_48k_plugin_geometry_fast_mode_as_benched(mode):
+    """prepareToPlay(48000, 1024) x 256 streams in VP_IIR_FAST / certified YIN -- bench.py's fs48k legs (round-5 verdict, item 3): frames
+    1112 / 834 (chunks of 278 samples: the block-form recursion's ragged last block, round 6), vocoder 556 / 139.  Sampled streams
+    against the oracle within the north_star tolerance with identical tracker states; the edge corpus (gate crossings, unvoiced
+    bursts, silence, an octave jump, clipping) rides in the batch's first streams; the exact mode on the same input is bit-exact."""
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    fs, N, B, S = 48000.0, 1024, 24, 256
+    x = _streams(S, N * B, fs=fs)
+    e = _edge_streams(N * B, fs=fs)
+    x[:e.shape[0]] = e
+    x = np.ascontiguousarray(x)
+    if mode == "pitch":
+        x[:, 1:] = 0
+    pick = list(range(e.shape[0])) + [37, 128, 255]
+    kw = dict(vocBool=0) if mode == "pitch" else {}
+    outs = {}
+    for iir in ("fast", "exact"):
+        p = BatchVocoderProcessor(**kw)
+        p.prepareToPlay(fs, N, S)
+        p.set_iir_mode(iir)
+        p.set_yin_mode("xcorr")
+        g = p.geometry()
+        assert (g["F"], g["H"], g["C"], g["W"], g["h"]) == (1112, 834, 278, 556, 139)
+        def decisions(s):                                                   # (the LPC coefficients are tolerance-mode arithmetic in VP_IIR_FAST)
+            d = p.pitch_state(s)
+            return [(k, d[k]) for k in ("period", "prevPeriod", "prevVoicedPeriod", "periodNew", "pitch", "prevPitch", "beta", "closestFreq", "gateOpen", "stMarkIdx", "anMarks", "stMarks")]
+        outs[iir] = (p.run(x), [decisions(s) for s in pick])
+        assert _timeouts(p) == [0, 0, 0]
+        p.close()
+    assert outs["fast"][1] == outs["exact"][1]                               # no decision depends on the recursions' or the LPC's arithmetic
+    for i, s in enumerate(pick):
+        o = O.OracleStream(**kw)
+        o.prepare_to_play(fs, N)
+        ref = o.run(x[s])
+        _assert_equal(outs["exact"][0][s], ref, f"{mode} stream {s} exact vs oracle")
+        err = outs["fast"][0][s].astype(np.float64) - ref
+        assert np.sqrt((err ** 2).mean()) < 1e-4 and np.abs(err).max() < 1e-3, (mode, s, np.sqrt((err ** 2).mean()), np.abs(err).max())
+    assert np.abs(outs["fast"][0]).max() > 0.05

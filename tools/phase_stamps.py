@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--block", type=int, default=1024)
     ap.add_argument("--iir", default="exact")
     ap.add_argument("--yin", default="direct")
+    ap.add_argument("--fs", type=float, default=44100.0, help="sample rate handed to prepareToPlay (48000: the plugin's other geometry, 1112/834 + 556/139)")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE configs[4] geometry: 48 kHz, 2048/1536 + 2048/512, orders 48/48/30, N = 2048")
     a = ap.parse_args()
     import torch
@@ -54,11 +55,11 @@ def main():
         p.prepareExplicit(48000.0, N, S, 2048, 1536, 2048, 512)
     else:
         p = BatchVocoderProcessor(pitchBool=int(a.mode != "voc"), vocBool=int(a.mode != "pitch"))
-        p.prepareToPlay(44100.0, N, S)
+        p.prepareToPlay(a.fs, N, S)
     p.set_iir_mode(a.iir)
     p.set_yin_mode(a.yin)
     U = 16
-    x = make_streams(S, N * U, fs=48000.0 if a.cfg5 else 44100.0, device="cuda").view(S, 3, U, N).permute(2, 0, 1, 3).contiguous()
+    x = make_streams(S, N * U, fs=48000.0 if a.cfg5 else a.fs, device="cuda").view(S, 3, U, N).permute(2, 0, 1, 3).contiguous()
     y = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
     for i in range(8):
         p.process_device(x[i % U], y)
