@@ -152,7 +152,7 @@ VP_HD static inline int vp_cum_len(int tauMax) { return tauMax + 1 > 448 ? tauMa
 // bytes of dynamic LDS vp_k_pitch needs for a geometry
 VP_HD static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
 {
-    size_t dbl = (size_t)(g.toKeep + g.F) + 4 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (g.htabGlobal ? 0 : 2 * (size_t)g.tauMax + 2);
+    size_t dbl = (size_t)(g.toKeep + g.F) + 12 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (g.htabGlobal ? 0 : 2 * (size_t)g.tauMax + 2);
     return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
 }
 // dynamic LDS of the analysis front end (vp_k_pitch_front): YIN window, prefix sums + quarter sums, yinTemp, running sum, r, a, scratch, state
