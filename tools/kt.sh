@@ -1,12 +1,15 @@
 #!/bin/bash
-# rocprofv3 kernel-trace of one bench configuration; prints our kernels' average durations.  usage: bash tools/kt.sh <tag> <bench args...>
+# usage: tools/kt.sh <tag> <bench args...>   -> gpurun_out/kt_<tag>.txt : per-kernel average durations (rocprofv3 --kernel-trace --stats)
 tag=$1; shift
-cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$tag -- python3 bench.py --no-cpu --single-mode --steps 40 --warmup 4 "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['value']/1e6,3), 'M frames/s', round(d['ms_per_step'],4), 'ms/step')"
-python3 - <<PY
-import csv,glob
-f=sorted(glob.glob('gpurun_out/kt_$tag/*/*kernel_stats.csv'))[-1]
-for r in csv.DictReader(open(f)):
-    if 'vp_k' in r['Name']:
-        print('   %-58s calls %s avg %.1f us min %.1f'%(r['Name'][:58], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3))
+cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+d=gpurun_out/kt_$tag; rm -rf $d; mkdir -p $d
+rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --steps 40 --warmup 4 --no-cpu --no-parity --single-mode "$@" > $d/bench.json 2> $d/err.txt
+f=$(find $d -name '*kernel_stats.csv' | head -1)
+python3 - "$f" > gpurun_out/kt_$tag.txt <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if r['Name'].startswith('vp_k') or r['Name'].startswith('void vp_k'):
+        print("%-60s calls %5s avg %9.1f us min %9.1f max %9.1f"%(r['Name'].split('(')[0][:60], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
 PY
+rm -rf $d
+cat gpurun_out/kt_$tag.txt
