@@ -790,7 +790,7 @@ def main():
         del q, xl, yl
         return out_
 
-    cfg2 = cfg3 = cfg4 = fs48 = None
+    cfg2 = cfg3 = cfg4 = fs48 = lpc24 = None
     k4 = max(120, args.steps // 2)                     # (a leg is tens of milliseconds: long enough for a stable figure whatever --steps is)
     if not args.single_mode and not args.cfg5 and BPS == 1:
         if not (mode == "voc" and args.lpc_voice == 24):
@@ -802,6 +802,9 @@ def main():
             cfg3 = leg("configs[3] per GPU: 1024 streams, pitch corrector + vocoder", "both", 1024, 44100.0, 1024, 256, None, {}, k4, with_exchange=True, blocks=8)
         cfg4 = leg("configs[4] per GPU: 512 streams @48 kHz, 2048-pt frames hop 512, orders 48/48/30, pitch corrector + vocoder", "both", 512,
                    48000.0, 2048, 512, (2048, 1536, 2048, 512), {"lpcVoice": 48, "lpcPitch": 48, "lpcSynth": 30}, max(64, args.steps // 3))
+
+        # configs[1] with lpcPitch 24 (cfg 2: "pP = 15 (also 24)"): the wave-specialised kernel's _o24 build (round 6)
+        lpc24 = leg("configs[1] with lpcPitch 24: 256 mono streams, pitch corrector", "pitch", 256, 44100.0, 1024, 256, None, {"lpcPitch": 24}, k4, mono_=True)
 
         # The reference's OTHER real geometry (round-5 verdict, item 3): what prepareToPlay(48000, 1024) picks (PluginProcessor.cpp:159-173:
         # pitch frames 1112 / hop 834 / chunk 278, vocoder window 556 / hop 139), 256 streams; a frame here is one 278-sample chunk.
@@ -873,6 +876,8 @@ def main():
             out["configs4"] = cfg4
         if fs48:
             out["fs48k"] = fs48
+        if lpc24:
+            out["configs1_lpcPitch24"] = lpc24
         if not args.single_mode:
             out["stft_kernel"] = stft_figure(dev, S)
         if n_gpus == 1 and not args.no_cpu:
@@ -891,6 +896,8 @@ def main():
             legs["configs3"] = brief(cfg3.get("parity"))
         if cfg4:
             legs["configs4"] = brief(cfg4.get("parity"))
+        if lpc24:
+            legs["lpcPitch24"] = brief(lpc24.get("parity"))
         if fs48:
             legs["fs48k_pitch"] = brief(fs48["pitch"].get("parity"))
             legs["fs48k_both"] = brief(fs48["both"].get("parity"))
@@ -919,6 +926,10 @@ def main():
             cf["configs4_value"] = cfg4["value"]
             cf["configs4_value_exact_mode"] = cfg4.get("value_exact_mode")
             cf["configs4_pitch_kernel"] = cfg4["kernel_builds"]["pitch"]
+        if lpc24:
+            cf["lpcPitch24_value"] = lpc24["value"]
+            cf["lpcPitch24_value_exact_mode"] = lpc24.get("value_exact_mode")
+            cf["lpcPitch24_kernel"] = lpc24["kernel_builds"]["pitch"]
         if fs48:
             cf["fs48k_pitch_value"] = fs48["pitch"]["value"]
             cf["fs48k_pitch_kernel"] = fs48["pitch"]["kernel_builds"]["pitch"]

@@ -418,3 +418,40 @@ def test_48k_plugin_geometry_fast_mode_as_benched(mode):
         err = outs["fast"][0][s].astype(np.float64) - ref
         assert np.sqrt((err ** 2).mean()) < 1e-4 and np.abs(err).max() < 1e-3, (mode, s, np.sqrt((err ** 2).mean()), np.abs(err).max())
     assert np.abs(outs["fast"][0]).max() > 0.05
+
+
+# ---- the wave-specialised kernel at lpcPitch 16 .. 24 ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N", [1024, 512, 256])
+@pytest.mark.parametrize("order", [16, 17, 24])
+@pytest.mark.parametrize("iir,yin", [("exact", "xcorr"), ("fast", "xcorr"), ("exact", "direct")])
+def test_wave_specialised_kernel_orders_16_to_24(order, iir, yin, N):
+    """lpcPitch up to 24 on vp_k_pitch_ws*_o24 (round-5 verdict, item 2c; SURVEY section 8 names 24 beside the default 15;
+    PluginProcessor.cpp:53-60 allows 2 .. 100): two groups of sixteen lags on the two LPC wavefronts, levinson_fast64 / levinson_row48,
+    128 samples of impulse response, the block recursion with its history matrix / the one-lane exact chain.  Same bits as the phase
+    kernels of that order (output, tracker state of every stream incl. the coefficients, UB-site counters), and in the exact mode
+    as the oracle."""
+    from vocoderproject_amd import BatchVocoderProcessor
+    x = _edge_streams(1024 * 24)
+    S = x.shape[0]
+    runs = {}
+    for ws in (True, False):
+        p = BatchVocoderProcessor(vocBool=0, lpcPitch=order)
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode(iir)
+        p.set_yin_mode(yin)
+        p.set_wave_specialised(ws)
+        name = p.pitch_kernel_name()
+        assert name == (("vp_k_pitch_ws_o24" if iir == "fast" else "vp_k_pitch_ws_x_o24") if ws else ("vp_k_pitch_fast" if iir == "fast" else "vp_k_pitch")), name
+        runs[ws] = (p.run(x), [_state_key(p, s) for s in range(S)], p.ub_counters())
+        assert _timeouts(p) == [0, 0, 0]
+        p.close()
+    _assert_equal(runs[True][0], runs[False][0], f"order {order} N={N} {iir}/{yin}: wave-specialised vs phase kernels")
+    assert runs[True][1:] == runs[False][1:]
+    assert np.abs(runs[True][0]).max() > 0.05
+    if iir == "exact":
+        from oracle import oracle_py as O
+        for s in range(S):
+            o = O.OracleStream(vocBool=0, lpcPitch=order)
+            o.prepare_to_play(FS, N)
+            _assert_equal(runs[True][0][s], o.run(x[s]), f"order {order} N={N} stream {s} vs oracle")

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # what `python bench.py` (configs[1] + the configs2/3/4 legs, FAST and EXACT IIR) launches
 BASELINE_KERNELS = [
     "vp_k_pitch_ws", "vp_k_pitch_ws_x",                       # configs[1]: 256 streams, pitch corrector (FAST / bit-exact), round 5
+    "vp_k_pitch_ws_o24", "vp_k_pitch_ws_x_o24",               # ... at lpcPitch 16 .. 24 (round 6)
     "vp_k_pitch_fast_c", "vp_k_pitch_c",                      # ... and the phase kernels they replaced there (still what larger host blocks launch)
     "vp_k_vocoder",                                           # configs[2]: 256 streams, vocoder, LPC order 24
     "vp_k_pitch_lite_fast_c", "vp_k_v2_ingest_stage", "vp_k_v2_autocorr<4, true>", "vp_k_v2_autocorr<8, true>", "vp_k_v2_autocorr<4, false>", "vp_k_v2_autocorr<8, false>", "vp_k_v2_levinson2<40, 8, true>", "vp_k_v2_levinson2<40, 8, false>",
@@ -65,7 +66,7 @@ def test_occupancy_two_for_the_full_register_builds(resources):
     for k in ("vp_k_pitch_lite_fast_c", "vp_k_vocoder_lite"):
         assert resources[k]["vgpr"] + resources[k]["agpr"] <= 128, (k, resources[k])
     # the wave-specialised kernels run twelve wavefronts per workgroup: three per SIMD
-    for k in ("vp_k_pitch_ws", "vp_k_pitch_ws_x"):
+    for k in ("vp_k_pitch_ws", "vp_k_pitch_ws_x", "vp_k_pitch_ws_o24", "vp_k_pitch_ws_x_o24"):
         assert resources[k]["vgpr"] + resources[k]["agpr"] <= 168 and resources[k]["scratch"] == 0, (k, resources[k])
 
 

@@ -209,10 +209,10 @@ static bool pitch_ws_ok(const vp_handle *h, bool fast, int nBlocks, int nSteps)
 {
     static const bool off = getenv("VP_NO_WS") != nullptr;
     const VpGeom &g = h->g;
-    // (its own geometric conditions: chunks of whole wavefronts up to 512 samples, lpcPitch <= 15 -- the row forms of Levinson-Durbin and of
-    // the recursions --, every lag on one wavefront, two 512-sample segments per frame for the FFT cross-correlation)
+    // (its own geometric conditions: chunks of whole wavefronts up to 512 samples, lpcPitch <= 24 -- the _o24 builds from 16 on, round 6 --,
+    // every lag on one wavefront, two 512-sample segments per frame for the FFT cross-correlation)
     if (off || !h->waveSpec || nBlocks != 1 || nSteps <= 0 || pitch_lite(h, fast) || g.F != 1024 || (g.C & 63) != 0 || g.C > 512 || g.cpf < 2 ||
-        g.orderPitch > 15 || g.tauMax > 512) return false;
+        g.orderPitch > WS_ORDER_MAX || g.tauMax > 512) return false;
     if ((size_t)(g.toKeep + g.F + (nSteps - 1) * g.C) >= (size_t)g.inSize) return false;
     if (nSteps + (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXI || (nSteps + g.cpf - 2) / (g.cpf - 1) + 1 > WS_MAXS) return false;   // (ws_build_sched's limits, whatever nChunk)
     return vp_pitch_ws_lds_bytes(g, nSteps) + 256 <= h->ldsMax;                 // (+ the kernels' static reduction slots: 384 bytes against the 256 ldsMax leaves)
@@ -236,7 +236,8 @@ extern "C" const char *vp_pitch_kernel_name(const vp_handle *h)
 {
     if (!h || !h->prepared) return "";
     const bool fast = h->iirMode == VP_IIR_FAST;
-    if (pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C)) return fast ? "vp_k_pitch_ws" : "vp_k_pitch_ws_x";
+    if (pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C))
+        return h->g.orderPitch > 15 ? (fast ? "vp_k_pitch_ws_o24" : "vp_k_pitch_ws_x_o24") : (fast ? "vp_k_pitch_ws" : "vp_k_pitch_ws_x");
     return pitch_plan(h, fast, 1).name;
 }
 
@@ -693,7 +694,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
                              (const void *)vp_k_pitch_front, (const void *)vp_k_pitch_front_fast,
-                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x,
+                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x, (const void *)vp_k_pitch_ws_o24, (const void *)vp_k_pitch_ws_x_o24,
                              (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -1092,7 +1093,8 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                     VpWsSched sc;
                     memset(&sc, 0, sizeof sc);
                     if (!ws_build_sched(g, cp.nChunk0, cp.nSteps, sc)) return fail_hip(h, hipErrorInvalidValue, "pitch schedule");   // (pitch_ws_ok's bounds rule this out)
-                    hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_ws : vp_k_pitch_ws_x, dim3(co.n), dim3(64 * wsWaves), (size_t)cp.ldsBytes, st, g, cp, d, sc, d_in, d_out);
+                    const auto wsk = g.orderPitch > 15 ? (cp.iirFast ? vp_k_pitch_ws_o24 : vp_k_pitch_ws_x_o24) : (cp.iirFast ? vp_k_pitch_ws : vp_k_pitch_ws_x);
+                    hipLaunchKernelGGL(wsk, dim3(co.n), dim3(64 * wsWaves), (size_t)cp.ldsBytes, st, g, cp, d, sc, d_in, d_out);
                 } else
                 hipLaunchKernelGGL(plan.fn, dim3(co.n), dim3(512), plan.lds, st, g, cp, d, d_in, d_out);
             }
