@@ -171,9 +171,10 @@ VP_HD static inline size_t vp_pitch_acc_lds_bytes(const VpGeom &g) { return ((si
 #define WS_MAXS 8                       // frame starts per block
 #define WS_NBG 4                        // background wavefronts
 #define WS_ORDER_MAX 24                 // lpcPitch the kernel serves (orders 16 .. 24: the _o24 builds, round 6)
-#define WS_AF 32                        // doubles per parity: the frame's coefficients where the residual and the recursions read them
-#define WS_HP 192                       // ... 64 zeros + the impulse response of 1/A(z) (64 samples; 128 for the orders above 16)
-#define WS_HIST 32                      // ... the exact recursion's history
+// doubles per parity (the orders up to 15 keep round 5's carve to the byte: blocks of five chunk steps still fit the CU's LDS):
+#define WS_AF(g) ((g).orderPitch > 15 ? 32 : 16)      // the frame's coefficients where the residual and the recursions read them
+#define WS_HP(g) ((g).orderPitch > 16 ? 192 : 128)    // 64 zeros + the impulse response of 1/A(z) (64 samples; 128 for the orders above 16)
+#define WS_HIST(g) ((g).orderPitch > 15 ? 32 : 16)    // the exact recursion's history
 
 struct WsCtl {                          // ints in LDS, zeroed by thread 0 in the prologue
     int psDone;                         // instances whose producer work is complete
@@ -255,10 +256,10 @@ VP_HD static inline WsCarve ws_carve(const VpGeom &g, int nSteps)
     o = ws_even(o);
     c.r = o;     o += 2 * 64;                                                  // per parity: r[0..15], the other half's sums at r[32..47]
     c.aPrev = o; o += 2 * (VP_ORDER_MAX + 1 + 1);                              // per parity: Levinson-Durbin's output
-    c.hp = o;    o += 2 * WS_HP;
-    c.aF = o;    o += 2 * WS_AF;
-    c.xp = o;    o += 128;
-    c.hist = o;  o += 2 * WS_HIST;
+    c.hp = o;    o += 2 * WS_HP(g);
+    c.aF = o;    o += 2 * WS_AF(g);
+    c.xp = o;    o += (g.orderPitch > 15 ? 128 : 64);
+    c.hist = o;  o += 2 * WS_HIST(g);
     c.tw = o;    o += 2 * VP_FFT_TW_D2;
     c.oA = o;    o += ws_even(g.N + g.C + 1);
     c.st = o;    o += 2 * ((int)(sizeof(VpPitchState) + 15) / 16 * 2);      // the producers' copy of the tracker state, the background's
