@@ -455,3 +455,124 @@ def test_wave_specialised_kernel_orders_16_to_24(order, iir, yin, N):
             o = O.OracleStream(vocBool=0, lpcPitch=order)
             o.prepare_to_play(FS, N)
             _assert_equal(runs[True][0][s], o.run(x[s]), f"order {order} N={N} stream {s} vs oracle")
+
+
+# ---- several queued blocks in one launch of the wave-specialised kernel ---------------------------------------------------------------
+
+@pytest.mark.parametrize("name,prepare,mono,dry", [
+    ("plugin_geometry_mono", None, True, False),
+    ("plugin_geometry_3ch_dry_paths", None, False, True),
+    ("N512_two_steps_per_block", (44100.0, 512, 1024, 768, 512, 128), True, False),
+    ("N256_one_step_per_block", (44100.0, 256, 1024, 768, 512, 128), False, False),
+    ("two_chunks_per_frame", (44100.0, 1024, 1024, 512, 512, 256), True, False),
+    ("eight_chunks_per_frame_N512", (44100.0, 512, 1024, 896, 512, 128), False, True),
+])
+def test_multi_block_launch_of_the_wave_specialised_kernel(name, prepare, mono, dry):
+    """vp_process_blocks*_device, pitch corrector alone, VP_IIR_FAST: groups of up to sixteen queued blocks in ONE launch of
+    vp_k_pitch_ws_mb (round-5 verdict, item 4) -- state, frame in flight, voice window and accumulator slice stay in LDS between the
+    blocks, the gate is updated incrementally.  Calls of 5, 16, 19 (16 + 3) and 2 blocks, single-block calls in between: the output,
+    the tracker state of every stream and the UB-site counters must equal a block-by-block run's bit for bit (edge corpus: gate
+    crossings, silence, unvoiced bursts), and no wait may run out."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    fs, N = (prepare[0], prepare[1]) if prepare else (FS, 1024)
+    plan = [5, 1, 16, 19, 1, 1, 2, 7]
+    B = sum(plan)
+    x = _edge_streams(N * B, fs=fs)
+    S = x.shape[0]
+    kw = dict(vocBool=0)
+    if dry:
+        kw.update(gainVoice=-12.0, gainSynth=-20.0)
+
+    def make():
+        p = BatchVocoderProcessor(**kw)
+        if prepare:
+            p.prepareExplicit(fs, N, S, *prepare[2:])
+        else:
+            p.prepareToPlay(fs, N, S)
+        p.set_iir_mode("fast")
+        p.set_yin_mode("xcorr")
+        for s_ in range(S):
+            p.setStreamParameter(s_, "keyPitch", [12, 0, 5, 7, 12, 3, 9, 1, 11][s_ % 9])
+        assert p.pitch_kernel_name() == "vp_k_pitch_ws"
+        return p
+
+    xd = torch.from_numpy(x).cuda()
+
+    def blocks(b0, n):
+        t = torch.stack([xd[:, :, (b0 + k) * N:(b0 + k + 1) * N] for k in range(n)])          # [n][S][3][N]
+        return t[:, :, 0, :].contiguous() if mono else t.contiguous()
+
+    ref_p = make()
+    ref = np.empty((S, 2, N * B), np.float32)
+    d_out = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
+    for b in range(B):
+        xb = blocks(b, 1)[0]
+        if mono:
+            ref_p.process_mono_device(xb, d_out)
+        else:
+            ref_p.process_device(xb, d_out)
+        ref[:, :, b * N:(b + 1) * N] = d_out.cpu().numpy()
+    ref_state = [_state_key(ref_p, s) for s in range(S)]
+    ref_ub = ref_p.ub_counters()
+    ref_p.close()
+
+    p = make()
+    p.reserve_blocks(max(plan))
+    p.profile_enable(1)
+    out = np.empty_like(ref)
+    b = 0
+    for n in plan:
+        xin = blocks(b, n)
+        if n == 1:
+            if mono:
+                p.process_mono_device(xin[0], d_out)
+            else:
+                p.process_device(xin[0], d_out)
+            out[:, :, b * N:(b + 1) * N] = d_out.cpu().numpy()
+        else:
+            yo = torch.empty((n, S, 2, N), dtype=torch.float32, device="cuda")
+            if mono:
+                p.process_blocks_mono_device(xin, yo)
+            else:
+                p.process_blocks_device(xin, yo)
+            o = yo.cpu().numpy()
+            for k in range(n):
+                out[:, :, (b + k) * N:(b + k + 1) * N] = o[k]
+        b += n
+    p.synchronize()
+    launches = p.profile_read()["vp_k_pitch_ws"][1]
+    if name == "eight_chunks_per_frame_N512":
+        assert launches == B - 1          # seven chunk steps per frame, four per block: seven distinct schedules > WS_MB_SCHEDS -> block by block
+    else:
+        assert launches == sum(1 if n == 1 else (n + 15) // 16 for n in plan), launches      # ONE launch per group of up to sixteen blocks
+    _assert_equal(out, ref, f"{name}: multi-block launches vs block by block")
+    assert [_state_key(p, s) for s in range(S)] == ref_state
+    assert p.ub_counters() == ref_ub
+    assert _timeouts(p) == [0, 0, 0]
+    assert np.abs(ref).max() > 0.05
+    p.close()
+
+
+def test_multi_block_launch_timeout_is_an_error():
+    """The multi-block launch keeps the timeouts-are-errors contract: one poll per wait -> VP_ERR_TIMEOUT at the next synchronisation."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor, VpError
+    N, S = 1024, 4
+    x = torch.from_numpy(_streams(S, N * 8)).cuda()
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode("fast")
+    p.set_yin_mode("xcorr")
+    p.reserve_blocks(8)
+    p.debug_set_spin_limit(1)
+    xin = torch.stack([x[:, 0, k * N:(k + 1) * N] for k in range(8)]).contiguous()
+    yo = torch.empty((8, S, 2, N), dtype=torch.float32, device="cuda")
+    code = None
+    try:
+        p.process_blocks_mono_device(xin, yo)
+        p.synchronize()
+    except VpError as e:
+        code = e.code
+    assert code == VP_ERR_TIMEOUT
+    p.close()

@@ -694,7 +694,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
                              (const void *)vp_k_pitch_front, (const void *)vp_k_pitch_front_fast,
-                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x, (const void *)vp_k_pitch_ws_o24, (const void *)vp_k_pitch_ws_x_o24,
+                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x, (const void *)vp_k_pitch_ws_mb, (const void *)vp_k_pitch_ws_o24, (const void *)vp_k_pitch_ws_x_o24,
                              (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -1354,6 +1354,76 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     return VP_OK;
 }
 
+// vp_process_blocks*_device, pitch corrector alone, where the wave-specialised kernel serves the geometry: up to WS_MB_MAX queued blocks
+// in ONE launch of vp_k_pitch_ws_mb (round 6) -- tracker state, frame in flight, voice window and output accumulator stay in LDS from
+// block to block.  Conditions beyond pitch_ws_ok: VP_IIR_FAST, lpcPitch <= 15, host blocks of whole chunks that start on the chunk grid
+// (every block then runs N / C steps), at most WS_MB_SCHEDS distinct schedules in the call (the plugin's geometry cycles through three).
+// Returns VP_OK + *done = false when the plan does not apply.
+static int process_ws_blocks(vp_handle *h, const float *d_in, float *d_out, int nb, hipStream_t st, bool mono, bool *done)
+{
+    *done = false;
+    static const bool off = getenv("VP_NO_WS_MB") != nullptr;
+    const VpGeom &g = h->g;
+    if (off || h->cohorts.size() != 1 || nb < 2 || nb > WS_MB_MAX || h->iirMode != VP_IIR_FAST || g.orderPitch > 15) return VP_OK;
+    auto &co = h->cohorts[0];
+    if (!co.pitchOn || co.vocOn || co.pStart != 0 || g.N % g.C != 0 || g.N < g.C) return VP_OK;
+    const int nSteps = g.N / g.C;
+    if (!pitch_ws_ok(h, true, 1, nSteps)) return VP_OK;
+    {   // what the kernel's block boundary is written for (ws_mb_boundary, vp_pitch_ws.inc): fixed trip counts of its 768 threads
+        const int nt = 768, span = g.toKeep + g.F + (nSteps - 1) * g.C;
+        if (g.N > 2 * nt || g.C > nt || span - g.N > 3 * nt || span < g.N || g.latency > g.F + (nSteps - 1) * g.C || g.latency < g.N) return VP_OK;
+    }
+    if (h->poisoned) return poisoned_rc(h);
+    if (int frc = check_fault(h)) return frc;
+    VpWsMb mb;
+    memset(&mb, 0, sizeof mb);
+    mb.nBlocks = nb;
+    int nSched = 0, schedChunk[WS_MB_SCHEDS];
+    int nChunk = co.nChunk, inC = h->inCounter, outC = h->outCounter, curC = h->currCounter;
+    for (int b = 0; b < nb; b++) {
+        int k = 0;
+        while (k < nSched && schedChunk[k] != nChunk) k++;
+        if (k == nSched) {
+            if (nSched == WS_MB_SCHEDS) return VP_OK;
+            if (!ws_build_sched(g, nChunk, nSteps, mb.sc[nSched])) return VP_OK;
+            schedChunk[nSched++] = nChunk;
+        }
+        mb.schedOf[b] = k; mb.nChunk0[b] = nChunk; mb.inCtr[b] = inC; mb.outCtr[b] = outC; mb.currCtr[b] = curC;
+        for (int i = 0; i < nSteps; i++) nChunk = (nChunk % g.cpf == g.cpf - 1) ? 1 % g.cpf : nChunk + 1;
+        inC = (inC + g.N) % g.inSize; outC = (outC + g.N) % g.outSize; curC = (curC + g.N) % g.inSize;
+    }
+    h->profThis = h->prof > 0 && (h->profTick++ % (unsigned)h->prof) == 0;
+    VpCall c;
+    memset(&c, 0, sizeof c);
+    c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
+    c.iirFast = 1; c.nBlocks = 1; c.pitchOn = 1; c.vocOn = 0;
+    c.pStart = 0; c.nChunk0 = co.nChunk; c.nSteps = nSteps;
+    c.fuseIngest = 1; c.fuseEmit = 1; c.ldsAcc = 1;
+    if (mono) {
+        c.inMono = h->synthNonZero > 0 ? 1 : 2;                               // (per launch: zeros are written while the ring may still hold anything else)
+        h->synthNonZero = std::max(0, h->synthNonZero - g.N * nb);
+    } else {
+        c.inMono = 0;
+        h->synthNonZero = g.inSize;
+    }
+    c.yinCert = (h->yinMode == VP_YIN_XCORR || h->yinMode == VP_YIN_FFT) ? 1 : (h->yinMode == VP_YIN_XCORR_FORCE_FALLBACK) ? 2 : 0;
+    c.ldsBytes = (int)vp_pitch_ws_lds_bytes(g, nSteps);
+    VpDev d = h->d;
+    d.streamMap = co.dMap;
+    d.outAcc2 = nullptr;
+    {
+        ProfScope ps(h, st, 2);
+        hipLaunchKernelGGL(vp_k_pitch_ws_mb, dim3(co.n), dim3(64 * 12), (size_t)c.ldsBytes, st, g, c, d, mb, d_in, d_out);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->poisoned = true; h->poisonCode = VP_ERR_HIP; return fail_hip(h, e, "kernel launch"); }
+    co.nChunk = nChunk;
+    h->inCounter = inC; h->outCounter = outC; h->currCounter = curC;
+    h->acc2Live = std::max(0, h->acc2Live - nb);
+    *done = true;
+    return VP_OK;
+}
+
 static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, int n_blocks, void *hip_stream, bool mono)
 {
     if (!h || !d_in || !d_out || n_blocks < 1) return VP_ERR_INVALID_ARG;
@@ -1370,6 +1440,19 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     // against 53.6 us per block at 256 streams -- and a block loop inside it did not pay: 51.4 us with eight wavefronts, 59.8 with twelve,
     // the loop level makes everything the programs derive from the geometry and the lane live across all of them)
     const bool wsBlocks = pitchOnly && !h->timeParallel && pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C);
+    if (wsBlocks && n_blocks > 1 && h->acc2Live == 0) {
+        // groups of up to WS_MB_MAX blocks per launch of the wave-specialised kernel; what the plan does not take goes block by block below
+        const size_t nIn_ = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut_ = (size_t)h->g.S * 2 * h->g.N;
+        while (n_blocks > 1) {
+            const int nb = std::min(n_blocks, WS_MB_MAX);
+            bool done = false;
+            rc = process_ws_blocks(h, d_in, d_out, nb, (hipStream_t)hip_stream, mono, &done);
+            if (rc) return rc;
+            if (!done) break;
+            d_in += nb * nIn_; d_out += nb * nOut_; n_blocks -= nb;
+        }
+        if (n_blocks == 0) return VP_OK;
+    }
     if (pitchOnly && n_blocks > 1 && !wsBlocks && (!pitch_lite(h, fast) || fast))
         return process_device(h, d_in, d_out, (hipStream_t)hip_stream, 0, n_blocks, mono);
     const size_t nIn = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut = (size_t)h->g.S * 2 * h->g.N;

@@ -236,6 +236,16 @@ VP_HD static inline bool ws_build_sched(const VpGeom &g, int nChunk0, int nSteps
     return nI > 0;
 }
 
+// Several queued blocks in ONE launch of the wave-specialised kernel (round 6, vp_k_pitch_ws_mb): per block of the call its counters and
+// which of the (few, cyclically recurring) schedules it runs -- all of it follows from the cohort's counters, so the host builds it.
+#define WS_MB_MAX 16
+#define WS_MB_SCHEDS 4
+struct VpWsMb {
+    int nBlocks;
+    int schedOf[WS_MB_MAX], nChunk0[WS_MB_MAX], inCtr[WS_MB_MAX], outCtr[WS_MB_MAX], currCtr[WS_MB_MAX];
+    VpWsSched sc[WS_MB_SCHEDS];
+};
+
 // dynamic LDS of the kernel: see the carve in pitch_ws_body (the host's vp_pitch_ws_lds_bytes mirrors it)
 struct WsCarve {
     int xs, eF, fr, qtab, htab, P, dY, gtab, r, aPrev, hp, aF, xp, hist, tw, oA, st, ctl, end;   // offsets in doubles
