@@ -82,7 +82,7 @@ def kernel_source_hash():
     """sha256 over what the kernels are built from: a counter file measured on other sources is not this build's."""
     h = hashlib.sha256()
     for rel in ("vocoderproject_amd/csrc/vp_kernels.hip", "vocoderproject_amd/csrc/vp_filters.inc", "vocoderproject_amd/csrc/vp_vocoder_wg.inc",
-                "vocoderproject_amd/csrc/vp_pitch.inc", "vocoderproject_amd/csrc/vp_pitch_ws.inc", "vocoderproject_amd/csrc/vp_fft.inc", "vocoderproject_amd/csrc/vp_fft32.inc", "vocoderproject_amd/csrc/vp_voc2.hip", "vocoderproject_amd/csrc/vp_common.h",
+                "vocoderproject_amd/csrc/vp_pitch.inc", "vocoderproject_amd/csrc/vp_pitch_ws.inc", "vocoderproject_amd/csrc/vp_pitch_ws_body.inc", "vocoderproject_amd/csrc/vp_fft.inc", "vocoderproject_amd/csrc/vp_fft32.inc", "vocoderproject_amd/csrc/vp_voc2.hip", "vocoderproject_amd/csrc/vp_common.h",
                 "vocoderproject_amd/csrc/vp_kernels.h", "vocoderproject_amd/csrc/vp_voc2.h", "vocoderproject_amd/csrc/vp_stft.hip",
                 "vocoderproject_amd/csrc/vp_stft.h", "vocoderproject_amd/build.py"):
         with open(os.path.join(ROOT, rel), "rb") as f:

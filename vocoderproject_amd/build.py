@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libvp_amd.so")
 SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_stft.hip", "vp_capi.hip"]
-PARTS = ["vp_fft.inc", "vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc", "vp_pitch_ws.inc"]      # included by vp_kernels.hip
+PARTS = ["vp_fft.inc", "vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc", "vp_pitch_ws.inc", "vp_pitch_ws_body.inc"]      # included by vp_kernels.hip
 DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h", "vp_stft.h", "vp_fft32.inc"]
 ARCH = "gfx950"
 NUM_TUS = 7          # groups of kernels in vp_kernels.hip (VP_TU)
