@@ -206,14 +206,12 @@ int vp_get_vocoder_path(const vp_handle *h);
 #define VP_OVERLAP_AUTO 2
 int vp_set_overlap(vp_handle *h, int on);
 int vp_get_overlap(const vp_handle *h);
-/* SURVEY 8(f2), time-parallel pitch front end (off by default).  With the switch on, a multi-block call (vp_process_blocks[_mono]_device,
- * pitch corrector only) first runs vp_k_pitch_front: yin() (PitchProcess.cpp:350-448) and the frame's LPC (LPC.cpp:44-148) for EVERY
- * frame that starts inside the call, one workgroup per (stream, frame) -- both depend on the input alone --, and the serial kernel then
- * reads a record per frame and goes straight to the marks.  Same routines, same modes, same bits as the block-by-block path
- * (tests/test_gpu_round3.py).  Measured: the serial kernel drops from 58 to 42 us per block at 256 streams,
- * the front end costs 15 us per block -- its cross-correlations are the same VALU work on the same CUs --, a wash at 256 streams
- * and a loss above, hence not the default.  Needs the plugin-like geometry (frame a multiple of 64 samples, tauMax <= 512,
- * lpcPitch < 64); ignored otherwise. */
+/* SURVEY 8(f2), queued audio.  What serves it (round 6): vp_process_blocks[_mono]_device hands the pitch corrector's blocks to ONE launch
+ * of vp_k_pitch_ws_mb per group of up to sixteen (state, frame in flight, voice window and accumulator slice stay on chip between the
+ * blocks; 27 M frames/s against 24 M block by block at 256 streams) -- no switch, same bits.  The earlier attempt, a time-parallel
+ * analysis front end in front of the serial kernel (vp_k_pitch_front, rounds 3-5), never paid -- its cross-correlations were the same
+ * vector work on the same CUs -- and was removed; the two entry points below are kept so that a version-2 caller links: the value is
+ * stored and returned, and changes nothing. */
 int vp_set_time_parallel(vp_handle *h, int on);
 int vp_get_time_parallel(const vp_handle *h);
 /* Round 5: which pitch-corrector kernel serves single-block calls of the plugin's own geometry (1024-sample frames, lpcPitch <= 15,

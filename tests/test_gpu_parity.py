@@ -525,11 +525,18 @@ def test_pitch_kernel_build_selection():
     w = BatchVocoderProcessor(vocBool=0)
     w.prepareToPlay(FS, 4096, 8)                                 # sixteen chunk steps per block: their voice window does not fit beside two frames
     assert w.pitch_kernel_name() == "vp_k_pitch_c"
-    g = BatchVocoderProcessor(vocBool=0, lpcPitch=24)            # an order the common-case builds do not cover
+    g = BatchVocoderProcessor(vocBool=0, lpcPitch=24)            # an order the common-case builds do not cover: the wave-specialised _o24 builds (round 6)
     g.prepareToPlay(FS, 1024, 8)
+    assert g.pitch_kernel_name() == "vp_k_pitch_ws_x_o24"
+    g.set_wave_specialised(False)
     assert g.pitch_kernel_name() == "vp_k_pitch"
     g.set_iir_mode("fast")
     assert g.pitch_kernel_name() == "vp_k_pitch_fast"
+    g.set_wave_specialised(True)
+    assert g.pitch_kernel_name() == "vp_k_pitch_ws_o24"
+    g2 = BatchVocoderProcessor(vocBool=0, lpcPitch=25)           # beyond WS_ORDER_MAX: the general phase kernels
+    g2.prepareToPlay(FS, 1024, 8)
+    assert g2.pitch_kernel_name() == "vp_k_pitch"
     q = BatchVocoderProcessor(vocBool=0)
     q.prepareToPlay(FS, 1024, 300)
     assert q.pitch_kernel_name() == "vp_k_pitch_lite"

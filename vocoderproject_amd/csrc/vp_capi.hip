@@ -65,7 +65,7 @@ struct vp_handle {
     double *acc2 = nullptr;
     int overlap = VP_OVERLAP_AUTO, acc2Live = 0;
     int waveSpec = 1;                           // vp_set_wave_specialised: vp_k_pitch_ws* where they apply (pitch_ws_ok)
-    int timeParallel = 0;                       // vp_set_time_parallel: multi-block pitch launches behind the analysis front end (vp_k_pitch_front)
+    int timeParallel = 0;                       // vp_set_time_parallel: stored and returned, without effect (the analysis front end it selected was removed in round 6)
     std::vector<void *> allocs;
     float *stageIn = nullptr, *stageOut = nullptr;
     int synthNonZero = 0;                       // samples of the synth rings not known to be zero (mono entry points)
@@ -174,15 +174,6 @@ static bool pitch_common_geom(const vp_handle *h)
 static bool pitch_common(const vp_handle *h)
 {
     return pitch_common_geom(h) && (h->g.F == 512 || h->g.F == 1024) && h->pitchLds + 16 + vp_pitch_fft_lds_bytes(2 * (h->g.F >> 9)) <= h->ldsMax;
-}
-
-// geometry and modes for which the analysis front end of multi-block launches (vp_k_pitch_front) can stand in for the serial kernel's
-// YIN phase: the eight-lag cross-correlation's layout (vp_pitch.inc xc8_ok), every LPC lag on one wavefront, 512-thread roles
-static bool pitch_front_ok(const vp_handle *h)
-{
-    const VpGeom &g = h->g;
-    return (g.F & 63) == 0 && (g.C & 1) == 0 && g.tauMax <= 512 && g.eLen >= g.F + 4 * g.tauMax + 1 && g.orderPitch < 64 &&
-           vp_pitch_front_lds_bytes(g) <= h->ldsMax && h->timeParallel;
 }
 
 // THE selection of the pitch-kernel build for a launch (used by the launch site and by vp_pitch_kernel_name alike)
@@ -693,7 +684,6 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
-                             (const void *)vp_k_pitch_front, (const void *)vp_k_pitch_front_fast,
                              (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x, (const void *)vp_k_pitch_ws_mb, (const void *)vp_k_pitch_ws_o24, (const void *)vp_k_pitch_ws_x_o24,
                              (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
@@ -717,7 +707,6 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
     RC(dev_alloc(h, &d.yFrame, (size_t)S * F));
     RC(dev_alloc(h, &d.EeArr, (size_t)S * 20));
     RC(dev_alloc(h, &d.hImp, (size_t)S * 128));
-    RC(dev_alloc(h, &d.front, (size_t)S * VP_FRONT_MAX));
     RC(dev_alloc(h, &d.ub, (size_t)5));
     RC(dev_alloc(h, &d.dbg, (size_t)64 + (size_t)S + 512));  // [64] phase timers / counters, then (diagnostic build) per-stream kernel ticks, then the
                                                              // wave-specialised pitch kernel's per-wavefront timers [4 block types][16 wavefronts][8]
@@ -1043,34 +1032,6 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cp.nBlocks = nBlocks;                          // > 1 only from process_blocks_device, pitch-only plan
                 ProfScope ps(h, st, 2);
                 PitchPlan plan = pitch_plan(h, cp.iirFast != 0, nBlocks);
-                if (nBlocks > 1 && pitch_front_ok(h)) {
-                    // yin() and the LPC of every frame that starts inside the launch, one workgroup per (stream, frame),
-                    // ahead of the serial kernel.  The frame starts follow from the counters (PitchProcess.cpp:166-196).
-                    VpFront fr;
-                    memset(&fr, 0, sizeof fr);
-                    int pS_ = co.pStart, nCh = co.nChunk;
-                    bool fits = true;
-                    for (int b = 0; b < nBlocks && fits; b++) {
-                        for (; pS_ < g.N; pS_ += g.C) {
-                            if (nCh == 0 || nCh == g.cpf - 1) {
-                                if (fr.nFr == VP_FRONT_MAX) { fits = false; break; }
-                                fr.start[fr.nFr++] = b * g.N + pS_;
-                                nCh = 0;
-                            }
-                            nCh += 1;
-                        }
-                        pS_ -= g.N;
-                    }
-                    if (fits && fr.nFr > 0) {
-                        VpCall cf = cp;
-                        const size_t fl = vp_pitch_front_lds_bytes(g);
-                        cf.fftOff = 0; cf.fftWaves = 0;                    // (the front end keeps the fused-multiply-add form: 128 registers)
-                        cf.ldsBytes = (int)fl;
-                        hipLaunchKernelGGL(cp.iirFast ? vp_k_pitch_front_fast : vp_k_pitch_front, dim3(co.n, fr.nFr), dim3(512), fl, st,
-                                           g, cf, d, fr, d_in);
-                        cp.front = 1;
-                    }
-                }
                 // one workgroup per CU anyway (S <= 256 or a frame beyond half a CU's LDS): the block's accumulator slice rides in LDS
                 // the block's accumulator slice in LDS when it fits beside the FFT cross-correlation's minimum (tables + one buffer)
                 const int fw = cp.yinCert ? pitch_xfft_waves(h, cp.iirFast != 0, nBlocks) : 0;
@@ -1087,7 +1048,7 @@ static int process_device(vp_handle *h, const float *d_in, float *d_out, hipStre
                 cp.ldsBytes = (int)plan.lds;
                 if (pitch_ws_ok(h, cp.iirFast != 0, nBlocks, cp.nSteps)) {
                     // the wave-specialised kernel: its own carve (the accumulator slice and the FFT's tables are part of it)
-                    cp.ldsAcc = 1; cp.fftOff = 0; cp.fftWaves = 0; cp.front = 0;
+                    cp.ldsAcc = 1; cp.fftOff = 0; cp.fftWaves = 0;
                     cp.ldsBytes = (int)vp_pitch_ws_lds_bytes(g, cp.nSteps);
                     static const int wsWaves = [] { const char *e = getenv("VP_WS_WAVES"); const int v = e ? atoi(e) : 0; return (v >= 8 && v <= 12) ? v : 12; }();   // (diagnostic: 8..12)
                     VpWsSched sc;
@@ -1434,12 +1395,11 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     if (rc) { h->poisoned = true; return rc; }
     const bool fast = h->iirMode == VP_IIR_FAST;
     const bool pitchOnly = h->cohorts.size() == 1 && h->cohorts[0].pitchOn && !h->cohorts[0].vocOn;
-    // one launch of the serial kernel for all the blocks (state stays on chip between them), behind the time-parallel analysis
-    // front end where the geometry allows it; above 256 streams the register-light builds exist for the FAST recursion only
-    // (round 5: where the wave-specialised kernel serves the geometry, a launch of it per block beats the one-launch phase kernel -- 44.8
-    // against 53.6 us per block at 256 streams -- and a block loop inside it did not pay: 51.4 us with eight wavefronts, 59.8 with twelve,
-    // the loop level makes everything the programs derive from the geometry and the lane live across all of them)
-    const bool wsBlocks = pitchOnly && !h->timeParallel && pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C);
+    // one launch of the serial kernel for all the blocks (state stays on chip between them); above 256 streams the register-light builds
+    // exist for the FAST recursion only.  Where the wave-specialised kernel serves the geometry: groups of up to sixteen blocks per launch
+    // of vp_k_pitch_ws_mb (round 6, process_ws_blocks; FAST, lpcPitch <= 15), else a launch of the single-block kernel per block (44.8
+    // against 53.6 us per block for the one-launch phase kernel at 256 streams, round 5)
+    const bool wsBlocks = pitchOnly && pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C);
     if (wsBlocks && n_blocks > 1 && h->acc2Live == 0) {
         // groups of up to WS_MB_MAX blocks per launch of the wave-specialised kernel; what the plan does not take goes block by block below
         const size_t nIn_ = (size_t)h->g.S * (mono ? 1 : 3) * h->g.N, nOut_ = (size_t)h->g.S * 2 * h->g.N;

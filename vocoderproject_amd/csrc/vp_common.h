@@ -58,7 +58,6 @@ struct VpCall {
     int nBlocks;                 // pitch kernel with both fusions: consecutive blocks handled by this launch (>= 1);
                                  // the counters above describe the first, the kernel advances them itself
     int pitchLin;                // pitch kernel, combined multi-block plan: gates to VpDev::gateB, no emit (see VpDev::pLin)
-    int front;                   // pitch kernel, multi-block launch: the frames' yin() and LPC come from vp_k_pitch_front's records
     int ldsAcc;                  // pitch kernel: the launch carries vp_pitch_acc_lds_bytes() more dynamic LDS, in which the block's
                                  // slice of the output accumulator lives while the chunks add to it (one read and one write
                                  // of HBM per block instead of a read-modify-write per chunk)
@@ -84,21 +83,7 @@ struct VpPitchState {
     VpStreamParams sp;
 };
 
-// Time-parallel analysis front end (vp_k_pitch_front): what PitchProcess::processChunkStart computes from the INPUT
-// alone (PitchProcess.cpp:203-233: yin() and the frame's LPC), for every frame that starts inside a multi-block launch, one
-// workgroup per (stream, frame); the serial kernel then only places marks and synthesises.
 #define VP_FFT_TW_D2 (64 + 512 + 256)   // complex doubles of the wavefront FFT's twiddle tables (vp_fft.inc)
-#define VP_FRONT_MAX 32              // frame starts per launch and stream the record array holds
-struct VpFrontRec {
-    double pitch;                    // yin(): fs / period, 0 = unvoiced (PitchProcess.cpp:411-448)
-    int period, zflag;               // zflag: levinsonDurbin took the |r0| < 1e-9 branch (the whole vector is [1, 0, ...], LPC.cpp:110-114)
-    double a[VP_ORDER_MAX + 1];      // the frame's A(z)
-    double h[128];                   // impulse response of 1/A(z) (block-form recursions)
-};
-struct VpFront {
-    int nFr;                         // frame starts in this launch (per stream: the schedule is the cohort's)
-    int start[VP_FRONT_MAX];         // their startSample, in samples from the launch's first block's logical index 0
-};
 
 struct VpDev {
     float *voiceRing;
@@ -121,7 +106,6 @@ struct VpDev {
     double *outAcc2;         // [S][outSize] second accumulator, non-null in the emit stage while it may hold anything: in
                              // VP_IIR_FAST mode the pitch corrector can run BESIDE the vocoder pipeline (another HIP stream) and
                              // then adds into this one; emit merges (and clears) both
-    VpFrontRec *front;       // [S][VP_FRONT_MAX] records of the analysis front end (multi-block launches)
     // combined multi-block plan (pitch corrector AND vocoder, several blocks per call, VP_IIR_FAST): the pitch kernel runs first, ingests
     // the blocks, leaves each block's two gates in gateB and adds its chunks into the LINEAR accumulator pLin (sample t of the call at
     // pLin[s][t]) instead of the accumulator ring; the vocoder pipeline then works from a snapshot of the rings as they stood before
@@ -154,13 +138,6 @@ VP_HD static inline size_t vp_pitch_lds_bytes(const VpGeom &g)
 {
     size_t dbl = (size_t)(g.toKeep + g.F) + 12 + (size_t)(g.xsSteps - 1) * g.C + g.eLen + 2 * (size_t)g.F + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + (2 * (size_t)g.tauMax + 4) + (g.htabGlobal ? 0 : 2 * (size_t)g.tauMax + 2);
     return dbl * sizeof(double) + 8 * 16 + sizeof(VpPitchState) + 64 + 64;
-}
-// dynamic LDS of the analysis front end (vp_k_pitch_front): YIN window, prefix sums + quarter sums, yinTemp, running sum, r, a, scratch, state
-VP_HD static inline size_t vp_pitch_front_lds_bytes(const VpGeom &g)
-{
-    const size_t nb = (size_t)g.F + g.tauMax;
-    size_t dbl = (nb + 42) + (nb + 2 + 3 * (size_t)g.tauMax + 2) + (size_t)vp_dy_len(g.tauMax) + (size_t)vp_cum_len(g.tauMax) + 2 * (VP_ORDER_MAX + 1) + 132 + 320;
-    return dbl * sizeof(double) + sizeof(VpPitchState) + 128;
 }
 // extra dynamic LDS for the block's slice of the output accumulator (VpCall::ldsAcc) and, behind it, a deferred chunk's input
 // and history (PitchLds::pend), placed behind vp_pitch_lds_bytes()

@@ -25,8 +25,6 @@ __global__ void vp_k_pitch_ws_x(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const
 __global__ void vp_k_pitch_ws_mb(VpGeom g, VpCall c, VpDev d, VpWsMb mb, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_ws_o24(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_ws_x_o24(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const float *__restrict__ in, float *__restrict__ out);
-__global__ void vp_k_pitch_front(VpGeom g, VpCall c, VpDev d, VpFront fr, const float *__restrict__ in);
-__global__ void vp_k_pitch_front_fast(VpGeom g, VpCall c, VpDev d, VpFront fr, const float *__restrict__ in);
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
 
 

@@ -225,7 +225,7 @@ class BatchVocoderProcessor:
         self._chk(self.L.vp_set_overlap(self.h, 2 if on == "auto" else int(bool(on))))
 
     def set_time_parallel(self, on):
-        """Multi-block pitch-only calls behind the time-parallel analysis front end (vp_k_pitch_front; off by default, see include/vp_amd.h)."""
+        """Kept for older callers: stored and returned, without effect (the analysis front end it selected was removed in round 6)."""
         self._chk(self.L.vp_set_time_parallel(self.h, int(bool(on))))
 
     def set_wave_specialised(self, on):
