@@ -298,6 +298,9 @@ def stft_figure(dev, S, T=1024 * 64, F=1024, hop=256, reps=30, pv=True, precisio
                          "frac_of_issue_slots": fps * insts * 64 / VALU_LANE_OPS_PEAK,
                          "what": "fp64 vector instructions per frame counted in the kernel's ISA (straight-line loop body) x frames/s, against "
                                  "78.6 TFLOP/s (FMA = 2) and against the fp64 issue slots (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz)"}}
+    # what really bounds the kernel: the issue of its fp64 vector instructions (HBM traffic is 1.03x algorithmic at 8 % of the peak)
+    out["roofline"]["real_bound"] = {"bound": "valu_issue", "frac": out["fp64_valu"]["frac_of_issue_slots"],
+                                     "what": "fp64 vector instructions per frame x frames/s against 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz"}
     ctr = committed_counters("vp_k_stft_fused<false, false>", f"stft/S{S}/T{T}/F{F}/hop{hop}")
     if ctr:                                                     # HBM bytes per launch from the committed PMC passes of this build (FETCH x 2 + WRITE)
         out["roofline"]["traffic"] = ctr.get("hbm_bytes_per_launch")
@@ -939,6 +942,7 @@ def main():
         if sk:
             cf["stft_frames_per_s"] = sk["frames_per_s"]
             cf["stft_hbm_frac"] = sk["roofline"]["frac"]
+            cf["stft_valu_issue_frac"] = sk.get("fp64_valu", {}).get("frac_of_issue_slots")
             cf["stft_f32_frames_per_s"] = sk.get("single_precision", {}).get("frames_per_s")
             cf["pv_frames_per_s"] = sk.get("phase_vocoder_frames_per_s")
         # the K timed blocks' mix of one- and two-start blocks beside the long-run mix (the timed region begins at a fixed phase)

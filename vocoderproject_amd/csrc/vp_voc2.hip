@@ -97,6 +97,8 @@ __device__ __forceinline__ V2EF v2_ef(const VpV2 &v, int w)
 // stretch of the ring, (nWin - 1) hop + W samples -- are first read into LDS with coalesced loads, and the tiles are built from there.
 // Read straight from the ring, a wavefront's 64 lanes (eight windows a hop apart x eight positions) touched 64 cache lines per load
 // instruction, eight instructions per tile entry: the kernel was bound by that gather (21.5 us for 86 MB at 1024 streams).
+// floats of padding per hop in the staged stretch (host and device): (hop + pad) = 33 mod 64
+__host__ __device__ static inline int v2_stage_pad(int hop) { return ((33 - hop) % 64 + 64) % 64; }
 __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &v, int spanLds)
 {
     extern __shared__ float v2_stage_lds[];
@@ -106,12 +108,20 @@ __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c,
     const int W4 = (g.W + 3) >> 2;
     const int span = (c.nWin - 1) * g.h + g.W;
     const bool viaLds = spanLds >= span && c.nWin > 0;
+    // (round 6) the staged stretch is PADDED per hop: sample t sits at t + (t / hop) pad, pad chosen so that consecutive windows -- a hop
+    // apart, i.e. a whole number of bank rows apart for the plugin's hops of 128 / 256 samples: the tile builder's eight windows x eight
+    // positions per wavefront met in eight banks, an 8-way conflict on every read (SQ_LDS_BANK_CONFLICT 3.9x the LDS-active cycles) --
+    // start 33 banks apart: at most two lanes of a read meet
+    const int hpad = viaLds ? v2_stage_pad(g.h) : 0;
+    const int hsh = (g.h & (g.h - 1)) == 0 ? __builtin_ctz(g.h) : -1;
+    auto lidx = [&](int t) -> int { return t + (hsh >= 0 ? t >> hsh : t / g.h) * hpad; };
     if (viaLds) {
         int p = ring_pos(c.currCounter, c.vStart + (int)threadIdx.x, g.inSize);
         const int step = blockDim.x % g.inSize;
         for (int t = threadIdx.x; t < span; t += blockDim.x) {
-            v2_stage_lds[t] = vr[p];
-            v2_stage_lds[spanLds + t] = sr0[p];
+            const int li = lidx(t);
+            v2_stage_lds[li] = vr[p];
+            v2_stage_lds[spanLds + li] = sr0[p];
             p += step;
             p -= (p >= g.inSize) ? g.inSize : 0;
         }
@@ -133,8 +143,9 @@ __device__ __forceinline__ void v2_stage_block(const VpGeom &g, const VpCall &c,
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const bool in = 4 * i4 + u < g.W;
-                a4[u] = in ? v2_stage_lds[q0 + u] : 0.0f;
-                b4[u] = in ? v2_stage_lds[spanLds + q0 + u] : 0.0f;
+                const int li = lidx(min(q0 + u, span - 1));
+                a4[u] = in ? v2_stage_lds[li] : 0.0f;
+                b4[u] = in ? v2_stage_lds[spanLds + li] : 0.0f;
             }
         } else {
         int p = ring_pos(c.currCounter, c.vStart + j * g.h + 4 * i4, g.inSize);
@@ -1042,7 +1053,9 @@ void vp_v2_launch(const VpGeom &g, const VpCall &c, const VpDev &d, const VpV2 &
 {
     const VpV2 &v = v_;
     // the staged stretch of the ring through LDS when two channels of it fit beside the kernel's static LDS (else straight from the ring)
-    const int span = (c.nWin - 1) * g.h + g.W, spanLds = (c.nWin > 0 && (size_t)2 * span * sizeof(float) <= 40 * 1024) ? ((span + 3) & ~3) : 0;
+    // (per channel: the stretch the block's windows cover, padded per hop -- v2_stage_pad)
+    const int span = (c.nWin - 1) * g.h + g.W, spanPad = span + (span / g.h + 1) * v2_stage_pad(g.h);
+    const int spanLds = (c.nWin > 0 && (size_t)2 * spanPad * sizeof(float) <= 48 * 1024) ? ((spanPad + 3) & ~3) : 0;
     V2_LAUNCH(vp_k_v2_ingest_stage, dim3(v.nStreams), dim3(256), (size_t)2 * spanLds * sizeof(float), g, c, d, v, d_in, spanLds);
     v2_launch_middle(g, c, d, v, st, beforeIir, hookArg);
     V2_LAUNCH(vp_k_v2_ola, dim3(v.nStreams), dim3(256), 0, g, c, d, v, d_out);
