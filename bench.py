@@ -90,7 +90,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def workload_key(cfg5, mode, mono, S, N, iir, yin, lpc_voice=None, voc_window=None, shift=None):
+def workload_key(cfg5, mode, mono, S, N, iir, yin, lpc_voice=None, voc_window=None, shift=None, bps=1):
     """Key of a (kernel, workload) pair in profiles/<tag>_counters.json; tools/summarize_counters.py builds the same one from the
     bench line's `config`.  The non-default vocoder order / window and the fixed shift are part of it: the profiled build must be
     the benched one (round-5 verdict, weak item 8)."""
@@ -101,6 +101,8 @@ def workload_key(cfg5, mode, mono, S, N, iir, yin, lpc_voice=None, voc_window=No
         k += "/w" + voc_window.replace("/", "-")
     if shift is not None:
         k += f"/shift{shift:g}"
+    if bps != 1:
+        k += f"/bps{bps}"                     # blocks per call (vp_process_blocks*_device): a launch then covers that many blocks
     return k
 
 
@@ -828,7 +830,7 @@ def main():
         dom_build = p.vocoder_kernel_name() if dom == "vp_k_vocoder" else p.pitch_kernel_name() if dom == "vp_k_pitch" else dom
         alg_bytes = ALG_BYTES_PER_FRAME[mode] * (HOP // 256) * frames_per_step_gpu      # f32 I/O per hop-frame (hop 512: twice the samples)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        wkey = workload_key(args.cfg5, mode, mono, S, N, args.iir, args.yin, args.lpc_voice, args.voc_window, args.shift)
+        wkey = workload_key(args.cfg5, mode, mono, S, N, args.iir, args.yin, args.lpc_voice, args.voc_window, args.shift, BPS)
         ctr = committed_counters(dom_build, wkey) if BPS == 1 else None
         roof = {"bound": "hbm", "kernel": dom_build, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": ctr["hbm_bytes_per_launch"] if ctr else None,
@@ -850,7 +852,7 @@ def main():
                                    f"{'pitch corrector (YIN+PSOLA on LPC residual, key=Chrom)' if mode == 'pitch' else 'LPC vocoder' if mode == 'voc' else 'pitch corrector + vocoder'}"
                                    f", 1024-pt frames hop 256, host block N={N}" + (f", {BPS} blocks per step" if BPS > 1 else "")
                                    + (f", lpcVoice {args.lpc_voice}" if args.lpc_voice else "") + (f", vocoder window {args.voc_window}" if args.voc_window else ""),
-                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "lpc_voice": args.lpc_voice, "voc_window": args.voc_window, "workload_key": workload_key(args.cfg5, mode, mono, S, N, args.iir, args.yin, args.lpc_voice, args.voc_window, args.shift), "input": "mono voice [S][N]" if mono else "[S][3][N]", "frames_per_step": frames_per_step_gpu * n_gpus,
+                       "streams_per_gpu": S, "block": N, "blocks_per_step": BPS, "mode": mode, "iir_mode": args.iir, "yin_mode": args.yin, "fixed_shift_semitones": args.shift, "lpc_voice": args.lpc_voice, "voc_window": args.voc_window, "workload_key": workload_key(args.cfg5, mode, mono, S, N, args.iir, args.yin, args.lpc_voice, args.voc_window, args.shift, BPS), "input": "mono voice [S][N]" if mono else "[S][3][N]", "frames_per_step": frames_per_step_gpu * n_gpus,
                        "kernel_builds": {"pitch": p.pitch_kernel_name() if mode != "voc" else None, "vocoder": p.vocoder_kernel_name() if mode != "pitch" else None},
                        "kernel_source_hash": kernel_source_hash(),
                        "parallelism": f"streams sharded over {n_gpus} GPU(s), one process per GPU, no data-path collective"},

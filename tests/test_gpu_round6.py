@@ -468,7 +468,23 @@ def test_wave_specialised_kernel_orders_16_to_24(order, iir, yin, N):
     ("eight_chunks_per_frame_N512", (44100.0, 512, 1024, 896, 512, 128), False, True),
 ])
 def test_multi_block_launch_of_the_wave_specialised_kernel(name, prepare, mono, dry):
-    """vp_process_blocks*_device, pitch corrector alone, VP_IIR_FAST: groups of up to sixteen queued blocks in ONE launch of
+    _multi_block_ws_case(name, prepare, mono, dry)
+
+
+@pytest.mark.parametrize("iir,order", [("exact", 15), ("fast", 24), ("exact", 24), ("exact", 16), ("fast", 17)])
+@pytest.mark.parametrize("name,prepare,mono,dry", [
+    ("plugin_geometry_mono", None, True, False),
+    ("N512_3ch_dry_paths", (44100.0, 512, 1024, 768, 512, 128), False, True),
+    ("two_chunks_per_frame", (44100.0, 1024, 1024, 512, 512, 256), True, False),
+])
+def test_multi_block_launch_exact_arithmetic_and_orders_to_24(name, prepare, mono, dry, iir, order):
+    """The same in the exact arithmetic (vp_k_pitch_ws_x_mb) and for lpcPitch 16 .. 24 (vp_k_pitch_ws_mb_o24 / _x_mb_o24); the exact
+    runs are, besides, bit-identical to the CPU oracle."""
+    _multi_block_ws_case(name, prepare, mono, dry, iir=iir, order=order)
+
+
+def _multi_block_ws_case(name, prepare, mono, dry, iir="fast", order=15):
+    """vp_process_blocks*_device, pitch corrector alone: groups of up to sixteen queued blocks in ONE launch of
     vp_k_pitch_ws_mb (round-5 verdict, item 4) -- state, frame in flight, voice window and accumulator slice stay in LDS between the
     blocks, the gate is updated incrementally.  Calls of 5, 16, 19 (16 + 3) and 2 blocks, single-block calls in between: the output,
     the tracker state of every stream and the UB-site counters must equal a block-by-block run's bit for bit (edge corpus: gate
@@ -480,9 +496,11 @@ def test_multi_block_launch_of_the_wave_specialised_kernel(name, prepare, mono, 
     B = sum(plan)
     x = _edge_streams(N * B, fs=fs)
     S = x.shape[0]
-    kw = dict(vocBool=0)
+    kw = dict(vocBool=0, lpcPitch=order)
     if dry:
         kw.update(gainVoice=-12.0, gainSynth=-20.0)
+    kernel = "vp_k_pitch_ws" + ("" if iir == "fast" else "_x") + ("_o24" if order > 15 else "")
+    keys = [12, 0, 5, 7, 12, 3, 9, 1, 11]
 
     def make():
         p = BatchVocoderProcessor(**kw)
@@ -490,11 +508,11 @@ def test_multi_block_launch_of_the_wave_specialised_kernel(name, prepare, mono, 
             p.prepareExplicit(fs, N, S, *prepare[2:])
         else:
             p.prepareToPlay(fs, N, S)
-        p.set_iir_mode("fast")
+        p.set_iir_mode(iir)
         p.set_yin_mode("xcorr")
         for s_ in range(S):
-            p.setStreamParameter(s_, "keyPitch", [12, 0, 5, 7, 12, 3, 9, 1, 11][s_ % 9])
-        assert p.pitch_kernel_name() == "vp_k_pitch_ws"
+            p.setStreamParameter(s_, "keyPitch", keys[s_ % 9])
+        assert p.pitch_kernel_name() == kernel
         return p
 
     xd = torch.from_numpy(x).cuda()
@@ -541,7 +559,7 @@ def test_multi_block_launch_of_the_wave_specialised_kernel(name, prepare, mono, 
                 out[:, :, (b + k) * N:(b + k + 1) * N] = o[k]
         b += n
     p.synchronize()
-    launches = p.profile_read()["vp_k_pitch_ws"][1]
+    launches = p.profile_read()[kernel][1]
     if name == "eight_chunks_per_frame_N512":
         assert launches >= B - 2          # seven chunk steps per frame, four per block: seven distinct schedules > WS_MB_SCHEDS -> block by block
     else:
@@ -552,6 +570,19 @@ def test_multi_block_launch_of_the_wave_specialised_kernel(name, prepare, mono, 
     assert _timeouts(p) == [0, 0, 0]
     assert np.abs(ref).max() > 0.05
     p.close()
+    if iir == "exact":
+        from oracle import oracle_py as O
+        for s_ in (0, S - 1):
+            o = O.OracleStream(**kw)
+            if prepare:
+                o.prepare_explicit(*[prepare[0], prepare[1]] + list(prepare[2:]))
+            else:
+                o.prepare_to_play(fs, N)
+            o.set_param("keyPitch", keys[s_ % 9])
+            xo = x[s_].copy()
+            if mono:
+                xo[1:] = 0.0                                   # (the mono entry points: null side-chain pointers, MyBuffer.cpp:93-102)
+            _assert_equal(out[s_], o.run(xo), f"{name} {iir} order {order}: stream {s_} vs oracle")
 
 
 def test_multi_block_launch_timeout_is_an_error():

@@ -29,6 +29,8 @@ sel=${2:-all}
 [ $sel = all -o $sel = cfg3 ] && run cfg3_voc_s256_lpc24_w1024 --mode voc --lpc-voice 24 --voc-window 1024/256
 # the +-12-semitone leg of configs[1]
 [ $sel = all -o $sel = cfg2s ] && run cfg2_pitch_s256_pm12 --shift 12
+# configs[1] with eight queued blocks per call: ONE vp_k_pitch_ws_mb launch covers them (its per-launch figures are per 8 blocks)
+[ $sel = all -o $sel = mb8 ] && run cfg2_pitch_s256_mb8 --blocks-per-step 8
 [ $sel = all -o $sel = cfg4 ] && run cfg4_both_s1024 --mode both --streams 1024
 [ $sel = all -o $sel = cfg5 ] && run cfg5_both_s512 --cfg5 --mode both --streams 512
 [ $sel = all -o $sel = cfg2x ] && run cfg2_pitch_s256_exact --iir exact

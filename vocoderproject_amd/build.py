@@ -23,7 +23,7 @@ SOURCES = ["vp_kernels.hip", "vp_voc2.hip", "vp_stft.hip", "vp_capi.hip"]
 PARTS = ["vp_fft.inc", "vp_filters.inc", "vp_vocoder_wg.inc", "vp_pitch.inc", "vp_pitch_ws.inc", "vp_pitch_ws_body.inc"]      # included by vp_kernels.hip
 DEPS = SOURCES + PARTS + ["vp_common.h", "vp_kernels.h", "vp_voc2.h", "vp_stft.h", "vp_fft32.inc"]
 ARCH = "gfx950"
-NUM_TUS = 7          # groups of kernels in vp_kernels.hip (VP_TU)
+NUM_TUS = 9          # groups of kernels in vp_kernels.hip (VP_TU)
 
 
 def hipcc():

@@ -684,7 +684,7 @@ extern "C" int vp_prepare_explicit(vp_handle *h, double fs, int N, int S, int F,
                              (const void *)vp_k_pitch_fast_multi, (const void *)vp_k_pitch_lite, (const void *)vp_k_pitch_lite_fast,
                              (const void *)vp_k_pitch_c, (const void *)vp_k_pitch_fast_c, (const void *)vp_k_pitch_fast_multi_c,
                              (const void *)vp_k_pitch_lite_fast_c, (const void *)vp_k_pitch_lite_fast_multi, (const void *)vp_k_pitch_lite_fast_multi_c,
-                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x, (const void *)vp_k_pitch_ws_mb, (const void *)vp_k_pitch_ws_o24, (const void *)vp_k_pitch_ws_x_o24,
+                             (const void *)vp_k_pitch_ws, (const void *)vp_k_pitch_ws_x, (const void *)vp_k_pitch_ws_mb, (const void *)vp_k_pitch_ws_x_mb, (const void *)vp_k_pitch_ws_mb_o24, (const void *)vp_k_pitch_ws_x_mb_o24, (const void *)vp_k_pitch_ws_o24, (const void *)vp_k_pitch_ws_x_o24,
                              (const void *)vp_k_vocoder, (const void *)vp_k_vocoder_o48, (const void *)vp_k_vocoder_lite};
         for (const void *f : fns) {
             hipFuncAttributes fa;
@@ -1316,8 +1316,8 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
 }
 
 // vp_process_blocks*_device, pitch corrector alone, where the wave-specialised kernel serves the geometry: up to WS_MB_MAX queued blocks
-// in ONE launch of vp_k_pitch_ws_mb (round 6) -- tracker state, frame in flight, voice window and output accumulator stay in LDS from
-// block to block.  Conditions beyond pitch_ws_ok: VP_IIR_FAST, lpcPitch <= 15, host blocks of whole chunks that start on the chunk grid
+// in ONE launch of vp_k_pitch_ws_mb / _x_mb / _mb_o24 / _x_mb_o24 (round 6) -- tracker state, frame in flight, voice window and output
+// accumulator stay in LDS from block to block.  Conditions beyond pitch_ws_ok: host blocks of whole chunks that start on the chunk grid
 // (every block then runs N / C steps), at most WS_MB_SCHEDS distinct schedules in the call (the plugin's geometry cycles through three).
 // Returns VP_OK + *done = false when the plan does not apply.
 static int process_ws_blocks(vp_handle *h, const float *d_in, float *d_out, int nb, hipStream_t st, bool mono, bool *done)
@@ -1325,11 +1325,12 @@ static int process_ws_blocks(vp_handle *h, const float *d_in, float *d_out, int 
     *done = false;
     static const bool off = getenv("VP_NO_WS_MB") != nullptr;
     const VpGeom &g = h->g;
-    if (off || h->cohorts.size() != 1 || nb < 2 || nb > WS_MB_MAX || h->iirMode != VP_IIR_FAST || g.orderPitch > 15) return VP_OK;
+    const bool fast = h->iirMode == VP_IIR_FAST;
+    if (off || h->cohorts.size() != 1 || nb < 2 || nb > WS_MB_MAX) return VP_OK;
     auto &co = h->cohorts[0];
     if (!co.pitchOn || co.vocOn || co.pStart != 0 || g.N % g.C != 0 || g.N < g.C) return VP_OK;
     const int nSteps = g.N / g.C;
-    if (!pitch_ws_ok(h, true, 1, nSteps)) return VP_OK;
+    if (!pitch_ws_ok(h, fast, 1, nSteps)) return VP_OK;
     {   // what the kernel's block boundary is written for (ws_mb_boundary, vp_pitch_ws.inc): fixed trip counts of its 768 threads
         const int nt = 768, span = g.toKeep + g.F + (nSteps - 1) * g.C;
         if (g.N > 2 * nt || g.C > nt || span - g.N > 3 * nt || span < g.N || g.latency > g.F + (nSteps - 1) * g.C || g.latency < g.N) return VP_OK;
@@ -1357,7 +1358,7 @@ static int process_ws_blocks(vp_handle *h, const float *d_in, float *d_out, int 
     VpCall c;
     memset(&c, 0, sizeof c);
     c.inCounter = h->inCounter; c.outCounter = h->outCounter; c.currCounter = h->currCounter;
-    c.iirFast = 1; c.nBlocks = 1; c.pitchOn = 1; c.vocOn = 0;
+    c.iirFast = fast ? 1 : 0; c.nBlocks = 1; c.pitchOn = 1; c.vocOn = 0;
     c.pStart = 0; c.nChunk0 = co.nChunk; c.nSteps = nSteps;
     c.fuseIngest = 1; c.fuseEmit = 1; c.ldsAcc = 1;
     if (mono) {
@@ -1374,7 +1375,8 @@ static int process_ws_blocks(vp_handle *h, const float *d_in, float *d_out, int 
     d.outAcc2 = nullptr;
     {
         ProfScope ps(h, st, 2);
-        hipLaunchKernelGGL(vp_k_pitch_ws_mb, dim3(co.n), dim3(64 * 12), (size_t)c.ldsBytes, st, g, c, d, mb, d_in, d_out);
+        const auto wsk = g.orderPitch > 15 ? (fast ? vp_k_pitch_ws_mb_o24 : vp_k_pitch_ws_x_mb_o24) : (fast ? vp_k_pitch_ws_mb : vp_k_pitch_ws_x_mb);
+        hipLaunchKernelGGL(wsk, dim3(co.n), dim3(64 * 12), (size_t)c.ldsBytes, st, g, c, d, mb, d_in, d_out);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->poisoned = true; h->poisonCode = VP_ERR_HIP; return fail_hip(h, e, "kernel launch"); }
@@ -1397,7 +1399,7 @@ static int process_blocks_device(vp_handle *h, const float *d_in, float *d_out, 
     const bool pitchOnly = h->cohorts.size() == 1 && h->cohorts[0].pitchOn && !h->cohorts[0].vocOn;
     // one launch of the serial kernel for all the blocks (state stays on chip between them); above 256 streams the register-light builds
     // exist for the FAST recursion only.  Where the wave-specialised kernel serves the geometry: groups of up to sixteen blocks per launch
-    // of vp_k_pitch_ws_mb (round 6, process_ws_blocks; FAST, lpcPitch <= 15), else a launch of the single-block kernel per block (44.8
+    // of vp_k_pitch_ws_mb (round 6, process_ws_blocks), else a launch of the single-block kernel per block (44.8
     // against 53.6 us per block for the one-launch phase kernel at 256 streams, round 5)
     const bool wsBlocks = pitchOnly && pitch_ws_ok(h, fast, 1, (h->g.N + h->g.C - 1) / h->g.C);
     if (wsBlocks && n_blocks > 1 && h->acc2Live == 0) {

@@ -23,6 +23,9 @@ __global__ void vp_k_pitch_lite_fast_multi_c(VpGeom g, VpCall c, VpDev d, const 
 __global__ void vp_k_pitch_ws(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_ws_x(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_ws_mb(VpGeom g, VpCall c, VpDev d, VpWsMb mb, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_ws_x_mb(VpGeom g, VpCall c, VpDev d, VpWsMb mb, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_ws_mb_o24(VpGeom g, VpCall c, VpDev d, VpWsMb mb, const float *__restrict__ in, float *__restrict__ out);
+__global__ void vp_k_pitch_ws_x_mb_o24(VpGeom g, VpCall c, VpDev d, VpWsMb mb, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_ws_o24(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_pitch_ws_x_o24(VpGeom g, VpCall c, VpDev d, VpWsSched sc, const float *__restrict__ in, float *__restrict__ out);
 __global__ void vp_k_emit(VpGeom g, VpCall c, VpDev d, float *__restrict__ out);
