@@ -207,7 +207,7 @@ int vp_get_vocoder_path(const vp_handle *h);
 int vp_set_overlap(vp_handle *h, int on);
 int vp_get_overlap(const vp_handle *h);
 /* SURVEY 8(f2), queued audio.  What serves it (round 6): vp_process_blocks[_mono]_device hands the pitch corrector's blocks to ONE launch
- * of vp_k_pitch_ws_mb per group of up to sixteen (state, frame in flight, voice window and accumulator slice stay on chip between the
+ * of vp_k_pitch_ws_mb (exact arithmetic: _x_mb; lpcPitch 16 .. 24: _mb_o24 / _x_mb_o24) per group of up to sixteen (state, frame in flight, voice window and accumulator slice stay on chip between the
  * blocks; 27 M frames/s against 24 M block by block at 256 streams) -- no switch, same bits.  The earlier attempt, a time-parallel
  * analysis front end in front of the serial kernel (vp_k_pitch_front, rounds 3-5), never paid -- its cross-correlations were the same
  * vector work on the same CUs -- and was removed; the two entry points below are kept so that a version-2 caller links: the value is
