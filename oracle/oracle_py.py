@@ -51,6 +51,51 @@ def build(force=False, asan=False):
     return path
 
 
+_REF_DIR = "/root/reference"
+_REF_NOTES = None
+
+
+def build_ref(force=False):
+    """oracle/_ref/libnotes_ref.so: the REFERENCE's own Source/Notes.cpp (the one translation unit that needs only the standard
+    library) compiled where it lies under /root/reference, behind a C binding (ref_notes_shim.cpp).  Only the build container has
+    /root/reference; elsewhere the prebuilt file is used if it travelled.  Returns its path, or None."""
+    path = os.path.join(_HERE, "_ref", "libnotes_ref.so")
+    if os.path.isdir(os.path.join(_REF_DIR, "Source")):
+        src = [os.path.join(_REF_DIR, "Source", "Notes.cpp"), os.path.join(_REF_DIR, "Source", "Notes.h"), os.path.join(_HERE, "ref_notes_shim.cpp")]
+        if force or not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "-s", "ref"])
+    return path if os.path.exists(path) else None
+
+
+class RefNotes:
+    """The reference's Notes object (Notes.h:20-44) through the binding: prepare (Notes.cpp:24-37), getClosestFreq (:79-110)."""
+
+    def __init__(self, key, f_min, f_max):
+        global _REF_NOTES
+        if _REF_NOTES is None:
+            p = build_ref()
+            if p is None:
+                raise FileNotFoundError("oracle/_ref/libnotes_ref.so is not built and /root/reference is not here")
+            R = C.CDLL(p)
+            R.refnotes_new.restype = C.c_void_p
+            R.refnotes_free.argtypes = [C.c_void_p]
+            R.refnotes_prepare.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+            R.refnotes_closest.argtypes = [C.c_void_p, C.c_double, C.c_int]
+            R.refnotes_closest.restype = C.c_double
+            _REF_NOTES = R
+        self.R = _REF_NOTES
+        self.h = self.R.refnotes_new()
+        self.R.refnotes_prepare(self.h, int(key), float(f_min), float(f_max))
+
+    def closest(self, pitch, key):
+        return self.R.refnotes_closest(self.h, float(pitch), int(key))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.R.refnotes_free(self.h)
+            self.h = None
+
+
 def lib():
     global _LIB
     if _LIB is None:

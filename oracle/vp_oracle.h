@@ -43,6 +43,10 @@
  *       sample t - 1024 + 697).  Where the two legitimately differ is counted and reported by the test: SURVEY Q5 (late grains
  *       dropped by the chunked synthesis), the residual samples that only the plugin has when it synthesises a frame's last
  *       chunk, int() vs round() of the new period, pitch > 10 vs > 1.
+ *     - pinned in round 6 against the REFERENCE ITSELF, compiled (oracle/_ref/libnotes_ref.so = /root/reference/Source/Notes.cpp -- the one
+ *       translation unit that needs only the standard library -- behind oracle/ref_notes_shim.cpp, built by `make ref` with
+ *       -include math.h): vpo_notes_build / vpo_notes_closest equal Notes::prepare / getClosestFreq bit for bit over all 13
+ *       keys (tests/test_oracle_ref_notes.py), and so does the device's lookup (tests/test_gpu_round6.py).
  *     - PARITY UNPINNED (what is left): the vocoder's 10-deep energy-history gain over several windows and its overlap-add
  *       (VocoderProcess.cpp:264-275, 291-327; one window at a time is pinned above), the mark branches methods.py does not
  *       share with the plugin (voiced->voiced without marks in the overlap; getClosestAnMarkIdx's incomplete-grain fallbacks

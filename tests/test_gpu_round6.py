@@ -607,3 +607,47 @@ def test_multi_block_launch_timeout_is_an_error():
         code = e.code
     assert code == VP_ERR_TIMEOUT
     p.close()
+
+
+# ---- the device's note lookup against the reference's own Notes.cpp, compiled (oracle/_ref) -------------------------------------------
+
+@pytest.mark.parametrize("ws", [True, False])
+@pytest.mark.parametrize("iir", ["exact", "fast"])
+def test_device_note_lookup_equals_the_compiled_reference(iir, ws):
+    """Notes::getClosestFreq (Notes.cpp:79-110) is the one piece of the path whose REFERENCE SOURCE compiles here (standard library only):
+    oracle/_ref/libnotes_ref.so is /root/reference/Source/Notes.cpp itself behind a C binding, built in the build container and carried
+    to this box.  After every block, for every stream whose last frame start was voiced, the tracker's closestFreq (place_st_marks /
+    notes_closest on the device, tables built by the host in vp_capi.hip) must be what the reference's Notes object returns for the
+    tracker's pitch in the stream's key -- all 13 keys, both kernel families, both arithmetic modes -- and beta their quotient."""
+    import torch
+    from oracle import oracle_py as O
+    from vocoderproject_amd import BatchVocoderProcessor
+    if O.build_ref() is None:
+        pytest.skip("oracle/_ref/libnotes_ref.so did not travel and /root/reference is not here")
+    S, N, B = 26, 1024, 14
+    x = _streams(S, N * B)
+    p = BatchVocoderProcessor(vocBool=0)
+    p.prepareToPlay(FS, N, S)
+    p.set_iir_mode(iir)
+    p.set_yin_mode("xcorr")
+    p.set_wave_specialised(ws)
+    keys = [s_ % 13 for s_ in range(S)]
+    refs = [O.RefNotes(k, 100.0, 800.0) for k in keys]
+    for s_ in range(S):
+        p.setStreamParameter(s_, "keyPitch", keys[s_])
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty((S, 2, N), dtype=torch.float32, device="cuda")
+    seen = 0
+    for b in range(B):
+        p.process_device(xd[:, :, b * N:(b + 1) * N].contiguous(), y)
+        p.synchronize()
+        for s_ in range(S):
+            st = p.pitch_state(s_)
+            if st["gateOpen"] and st["pitch"] > 1:
+                want = refs[s_].closest(st["pitch"], keys[s_])
+                assert st["closestFreq"] == want, f"block {b} stream {s_} key {keys[s_]}: pitch {st['pitch']!r}: device {st['closestFreq']!r}, reference {want!r}"
+                assert st["beta"] == want / st["pitch"]
+                seen += 1
+    assert seen > S * B // 2, seen
+    assert _timeouts(p) == [0, 0, 0]
+    p.close()

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--yin", default="direct")
     ap.add_argument("--fs", type=float, default=44100.0, help="sample rate handed to prepareToPlay (48000: the plugin's other geometry, 1112/834 + 556/139)")
     ap.add_argument("--cfg5", action="store_true", help="BASELINE configs[4] geometry: 48 kHz, 2048/1536 + 2048/512, orders 48/48/30, N = 2048")
+    ap.add_argument("--lpc-voice", type=int, default=None, help="lpcVoice (BASELINE configs[2]: 24)")
     a = ap.parse_args()
     import torch
     from vocoderproject_amd import BatchVocoderProcessor
@@ -54,7 +55,8 @@ def main():
         p = BatchVocoderProcessor(pitchBool=int(a.mode != "voc"), vocBool=int(a.mode != "pitch"), lpcVoice=48, lpcPitch=48, lpcSynth=30)
         p.prepareExplicit(48000.0, N, S, 2048, 1536, 2048, 512)
     else:
-        p = BatchVocoderProcessor(pitchBool=int(a.mode != "voc"), vocBool=int(a.mode != "pitch"))
+        kw = dict(lpcVoice=a.lpc_voice) if a.lpc_voice else {}
+        p = BatchVocoderProcessor(pitchBool=int(a.mode != "voc"), vocBool=int(a.mode != "pitch"), **kw)
         p.prepareToPlay(a.fs, N, S)
     p.set_iir_mode(a.iir)
     p.set_yin_mode(a.yin)
