@@ -651,3 +651,43 @@ def test_device_note_lookup_equals_the_compiled_reference(iir, ws):
     assert seen > S * B // 2, seen
     assert _timeouts(p) == [0, 0, 0]
     p.close()
+
+
+def test_combined_plan_small_groups_go_block_by_block(monkeypatch):
+    """vp_process_blocks_device, pitch corrector + vocoder on a large batch (the lane-per-window pipeline): the multi-block plan has a fixed
+    cost per call (two ring snapshots, a separate ingest) that made calls of 2 / 4 blocks SLOWER than block by block (310 / 286 against
+    275-280 us per block at 1024 streams).  By default only groups of eight blocks and more take it; the environment variable the suite
+    sets (conftest.py) lowers the threshold.  Same output either way."""
+    import torch
+    from vocoderproject_amd import BatchVocoderProcessor
+    S, N, nb = 260, 1024, 4
+    x = np.ascontiguousarray(np.tile(_streams(13, N * 2 * nb), (20, 1, 1)))
+    xd = torch.from_numpy(x).cuda()
+
+    def run():
+        p = BatchVocoderProcessor()
+        p.prepareToPlay(FS, N, S)
+        p.set_iir_mode("fast")
+        p.set_yin_mode("xcorr")
+        p.reserve_blocks(nb)
+        p.profile_enable(1)
+        outs = []
+        for c_ in range(2):
+            xin = torch.stack([xd[:, :, (c_ * nb + k) * N:(c_ * nb + k + 1) * N] for k in range(nb)]).contiguous()
+            yo = torch.empty((nb, S, 2, N), dtype=torch.float32, device="cuda")
+            p.process_blocks_device(xin, yo)
+            outs.append(yo.cpu().numpy())
+        p.synchronize()
+        launches = p.profile_read()[p.pitch_kernel_name()][1]
+        p.close()
+        return np.concatenate(outs), launches
+
+    monkeypatch.setenv("VP_BOTH_MB_MIN", "2")
+    y_plan, n_plan = run()
+    monkeypatch.delenv("VP_BOTH_MB_MIN")
+    y_def, n_def = run()
+    assert n_plan == 2, n_plan                     # one pitch launch per call
+    assert n_def == 2 * nb, n_def                  # the default: block by block
+    assert np.abs(y_plan).max() > 0.01
+    d = np.abs(y_plan.astype(np.float64) - y_def)
+    assert d.max() <= 4e-7 * max(1.0, float(np.abs(y_def).max())), d.max()

@@ -1228,6 +1228,12 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     *done = false;
     const VpGeom &g = h->g;
     if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX || h->iirMode != VP_IIR_FAST) return VP_OK;
+    // (round 6, measured at 1024 streams and at the configs[4] geometry: the plan's fixed cost per call -- the two ring snapshots, the
+    // separate ingest -- makes calls of 2 blocks 11 % SLOWER than block by block (310 against 275-280 us per block; 4 blocks: 283-286;
+    // 8: 279, and 375 against 381 at the configs[4] geometry): groups of fewer than eight blocks go block by block)
+    // (VP_BOTH_MB_MIN: the test suite sets it to 2 so that its short calls keep exercising the plan; read per call -- a multi-block call is
+    // hundreds of microseconds)
+    { const char *e = getenv("VP_BOTH_MB_MIN"); const int v = e ? atoi(e) : 0; if (nb < (v >= 2 ? v : 8)) return VP_OK; }
     auto &co = h->cohorts[0];
     // only where single-block calls run the pipeline too (VP_VOC_AUTO: batches above 256 streams; VP_VOC_BATCHED): the vocoder's
     // arithmetic must not depend on how the caller groups blocks (voc_auto_batched: "decided ONCE per prepare")
