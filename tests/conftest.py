@@ -8,9 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The combined (pitch + vocoder) multi-block plan of vp_process_blocks_device only takes groups of eight blocks and more by default (round 6:
-# shorter calls measured slower than block by block, vp_capi.hip process_both_blocks).  The suite's calls are short: it lowers the
-# threshold so that they keep exercising the plan; test_combined_plan_small_groups_go_block_by_block checks the default.
+# The multi-block plans of the lane-per-window pipeline (vp_process_blocks_device) follow the batch size by default (round 6: where one
+# block's windows fill the chip, short calls measured slower than block by block; vp_capi.hip v2_mb_min_blocks).  The suite's calls are
+# short and some of its batches large: it forces the plans so that they stay exercised;
+# test_pipeline_multi_block_plans_follow_the_batch_size checks the default.
 os.environ.setdefault("VP_BOTH_MB_MIN", "2")
 
 

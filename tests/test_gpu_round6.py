@@ -653,19 +653,21 @@ def test_device_note_lookup_equals_the_compiled_reference(iir, ws):
     p.close()
 
 
-def test_combined_plan_small_groups_go_block_by_block(monkeypatch):
-    """vp_process_blocks_device, pitch corrector + vocoder on a large batch (the lane-per-window pipeline): the multi-block plan has a fixed
-    cost per call (two ring snapshots, a separate ingest) that made calls of 2 / 4 blocks SLOWER than block by block (310 / 286 against
-    275-280 us per block at 1024 streams).  By default only groups of eight blocks and more take it; the environment variable the suite
-    sets (conftest.py) lowers the threshold.  Same output either way."""
+def test_pipeline_multi_block_plans_follow_the_batch_size(monkeypatch):
+    """vp_process_blocks_device on the lane-per-window pipeline: where ONE block's windows already fill the chip (a lane per window: 8192
+    windows and more per block, 1040 streams here) more blocks per launch only add the plans' fixed costs -- measured: the vocoder-only plan loses at every
+    group size, the combined plan breaks even at eight blocks (profiles/r06_blocks_per_call.txt) -- so short calls go block by block there;
+    smaller batches (260 streams) are short of wavefronts and take the plans from two blocks on.  The environment variable the suite sets
+    (conftest.py) forces the plans.  Same output either way."""
     import torch
     from vocoderproject_amd import BatchVocoderProcessor
-    S, N, nb = 260, 1024, 4
-    x = np.ascontiguousarray(np.tile(_streams(13, N * 2 * nb), (20, 1, 1)))
-    xd = torch.from_numpy(x).cuda()
+    N, nb = 1024, 4
+    base = _streams(13, N * 2 * nb)
 
-    def run():
-        p = BatchVocoderProcessor()
+    def run(S, pitch):
+        x = np.ascontiguousarray(np.tile(base, (S // 13, 1, 1)))
+        xd = torch.from_numpy(x).cuda()
+        p = BatchVocoderProcessor(pitchBool=int(pitch))
         p.prepareToPlay(FS, N, S)
         p.set_iir_mode("fast")
         p.set_yin_mode("xcorr")
@@ -678,16 +680,19 @@ def test_combined_plan_small_groups_go_block_by_block(monkeypatch):
             p.process_blocks_device(xin, yo)
             outs.append(yo.cpu().numpy())
         p.synchronize()
-        launches = p.profile_read()[p.pitch_kernel_name()][1]
+        prof = p.profile_read()
+        launches = prof[p.pitch_kernel_name()][1] if pitch else prof["vp_k_vocoder"][1]
         p.close()
         return np.concatenate(outs), launches
 
-    monkeypatch.setenv("VP_BOTH_MB_MIN", "2")
-    y_plan, n_plan = run()
-    monkeypatch.delenv("VP_BOTH_MB_MIN")
-    y_def, n_def = run()
-    assert n_plan == 2, n_plan                     # one pitch launch per call
-    assert n_def == 2 * nb, n_def                  # the default: block by block
-    assert np.abs(y_plan).max() > 0.01
-    d = np.abs(y_plan.astype(np.float64) - y_def)
-    assert d.max() <= 4e-7 * max(1.0, float(np.abs(y_def).max())), d.max()
+    for pitch in (True, False):
+        monkeypatch.setenv("VP_BOTH_MB_MIN", "2")
+        y_plan, n_plan = run(1040, pitch)
+        monkeypatch.delenv("VP_BOTH_MB_MIN")
+        y_def, n_def = run(1040, pitch)
+        _, n_small = run(260, pitch)
+        assert n_plan < n_def, (pitch, n_plan, n_def)              # the plan: one pass per call; the default at this size: block by block
+        assert n_small == n_plan, (pitch, n_small, n_plan)         # a batch that does not fill the chip takes the plan by default
+        assert np.abs(y_plan).max() > 0.01
+        d = np.abs(y_plan.astype(np.float64) - y_def)
+        assert d.max() <= 4e-7 * max(1.0, float(np.abs(y_def).max())), (pitch, d.max())

@@ -1137,6 +1137,24 @@ static int ensure_v2mb(vp_handle *h, int nWin)
 
 // vp_process_blocks_device, vocoder-only plan on the batched pipeline: up to V2_MB_MAX consecutive blocks as ONE launch of the
 // pipeline (B times the windows = B times the lanes; vp_voc2.hip).  Returns VP_OK + *done = false when the plan does not apply.
+// Smallest group of blocks the multi-block plans of the lane-per-window pipeline take (round 6, measured: profiles/r06_blocks_per_call.txt;
+// 0: never).  The pipeline's kernels launch a lane per WINDOW: with 8192 windows per block (1024 streams at 512 / 128) one block fills the
+// chip, and more blocks per launch only add the plans' fixed costs (ring snapshots, dry-path staging) and push the tiles out of the
+// Infinity Cache -- the vocoder-only plan then loses at every group size (118 us per block alone; 134 / 131 / 133 with 2 / 4 / 8), the
+// combined plan breaks even at eight (307 / 284 / 279 against 275-277).  With fewer windows the launches are short of wavefronts and the
+// plans pay from two blocks on (512 streams: vocoder 87.7 -> 75.8 / 71.4 / 68.0 us per block, both 170.9 -> 162.5 / 153.0 / 144.9; the
+// configs[4] geometry, 2048 windows of 2048 samples: vocoder 198 -> 184 / 162 / 168) -- except that the combined plan has no pitch kernel
+// beside the pipeline's tail, so where single-block calls have one (VP_OVERLAP_AUTO, the full-register pitch builds: configs[4]) it
+// too needs eight blocks to break even (416 / 377 / 374 against 378).  VP_BOTH_MB_MIN overrides (the test suite: 2).
+static int v2_mb_min_blocks(const vp_handle *h, const vp_handle::Cohort &co, bool both)
+{
+    if (const char *e = getenv("VP_BOTH_MB_MIN")) { const int v = atoi(e); if (v >= 2) return v; }
+    const bool full = (size_t)co.n * (size_t)h->nWinMax >= 8192;
+    if (!both) return full ? 0 : 2;
+    const bool tailOverlap = h->overlap == 1 || (h->overlap == VP_OVERLAP_AUTO && !pitch_lite(h, true));
+    return (full || tailOverlap) ? 8 : 2;
+}
+
 static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int nb, hipStream_t st, bool *done)
 {
     *done = false;
@@ -1144,6 +1162,7 @@ static int process_voc_blocks(vp_handle *h, const float *d_in, float *d_out, int
     if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX) return VP_OK;
     auto &co = h->cohorts[0];
     if (!co.vocOn || co.pitchOn || !h->v2.xT || h->vocPath == VP_VOC_WORKGROUP) return VP_OK;
+    { const int mn = v2_mb_min_blocks(h, co, false); if (mn == 0 || nb < mn) return VP_OK; }
     // VP_IIR_FAST: the pipeline's and the workgroup kernel's tolerance-mode roundings differ, so the plan only runs where single-block
     // calls take the pipeline too (the output must not depend on how the caller groups blocks); VP_IIR_EXACT: both give the same bits
     if (h->iirMode == VP_IIR_FAST && !voc_pipeline_wanted(h)) return VP_OK;
@@ -1228,12 +1247,7 @@ static int process_both_blocks(vp_handle *h, const float *d_in, float *d_out, in
     *done = false;
     const VpGeom &g = h->g;
     if (h->cohorts.size() != 1 || nb < 2 || nb > V2_MB_MAX || h->iirMode != VP_IIR_FAST) return VP_OK;
-    // (round 6, measured at 1024 streams and at the configs[4] geometry: the plan's fixed cost per call -- the two ring snapshots, the
-    // separate ingest -- makes calls of 2 blocks 11 % SLOWER than block by block (310 against 275-280 us per block; 4 blocks: 283-286;
-    // 8: 279, and 375 against 381 at the configs[4] geometry): groups of fewer than eight blocks go block by block)
-    // (VP_BOTH_MB_MIN: the test suite sets it to 2 so that its short calls keep exercising the plan; read per call -- a multi-block call is
-    // hundreds of microseconds)
-    { const char *e = getenv("VP_BOTH_MB_MIN"); const int v = e ? atoi(e) : 0; if (nb < (v >= 2 ? v : 8)) return VP_OK; }
+    { const int mn = v2_mb_min_blocks(h, h->cohorts[0], true); if (mn == 0 || nb < mn) return VP_OK; }
     auto &co = h->cohorts[0];
     // only where single-block calls run the pipeline too (VP_VOC_AUTO: batches above 256 streams; VP_VOC_BATCHED): the vocoder's
     // arithmetic must not depend on how the caller groups blocks (voc_auto_batched: "decided ONCE per prepare")
