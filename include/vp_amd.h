@@ -155,6 +155,11 @@ int vp_process_blocks_mono_device(vp_handle *h, const float *d_voice, float *d_o
  *    every decision and every filter output is the block-by-block path's; the audio equals it to the rounding of the additions
  *    into the output accumulator, which happen chunks-first instead of windows-first (<= 2e-6 of full scale, tested);
  *  - anything else (VP_IIR_EXACT with both enabled, per-stream switches that split the batch, ...): block by block.
+ * The two pipeline plans are only taken where they pay (round 6, measured): a batch whose single block already fills the chip
+ * (8192 windows and more per block: e.g. 1024 streams at 512 / 128) runs the vocoder-only plan never and the combined plan from
+ * groups of eight blocks on -- as does a batch whose single-block calls overlap the pitch kernel with the pipeline's tail
+ * (vp_set_overlap) --; smaller batches take both from two blocks on.  Same results either way (the plans' arithmetic is the
+ * single-block pipeline's).
  * The two pipeline plans need scratch for the call's windows: vp_reserve_blocks(h, n) sizes it for calls of up to n blocks; a
  * larger call is carried out in groups of n, and without a reservation these plans fall back to block by block.  Nothing is
  * allocated here. */
